@@ -1,0 +1,125 @@
+// Pointwise helper stencils: saturation, state_increment, perturbed_state.
+//   saturation       /root/reference/src/cloudsc2_gt4py/physics/common/_stencils/saturation.py:23-42
+//                    (+ f_foealfa / f_foeewm / f_foeewmcu, common/_stencils/fcttre.py:22-57)
+//   state_increment  /root/reference/src/cloudsc2_gt4py/physics/common/_stencils/state_increment.py:61-80
+//   perturbed_state  /root/reference/src/cloudsc2_gt4py/physics/common/_stencils/perturbed_state.py:75-91
+// All three are pure streaming kernels: grid.y walks the levels, grid.x the columns, so each wave
+// issues fully coalesced row segments of the [level][column] storage.
+#include "cloudsc2_common.hpp"
+
+namespace cs2 {
+
+constexpr int kAuxBlock = 256;
+
+template <typename T>
+__device__ __forceinline__ T foealfa(const Ext<T>& e, T t) {
+    return rmin<T>(T(1.0), sq((rmax<T>(e.RTICE, rmin<T>(e.RTWAT, t)) - e.RTICE) * e.RTWAT_RTICE_R));
+}
+template <typename T>
+__device__ __forceinline__ T foealfcu(const Ext<T>& e, T t) {
+    return rmin<T>(T(1.0), sq((rmax<T>(e.RTICECU, rmin<T>(e.RTWAT, t)) - e.RTICECU) * e.RTWAT_RTICECU_R));
+}
+
+// MODE 0: LPHYLIN; MODE 1: not LPHYLIN, KFLAG == 1 (f_foeewmcu); MODE 2: not LPHYLIN, KFLAG != 1 (f_foeewm)
+template <typename T, int MODE>
+__global__ void __launch_bounds__(kAuxBlock)
+saturation_kernel(Ext<T> e, int nx, int64_t ls, const T* __restrict__ ap, const T* __restrict__ t,
+                  T* __restrict__ qsat) {
+    const int col = blockIdx.x * kAuxBlock + threadIdx.x;
+    if (col >= nx) return;
+    const int64_t i = int64_t(blockIdx.y) * ls + col;
+    const T tt = t[i];
+    const T foeewl = rexp<T>(e.R3LES * (tt - e.RTT) / (tt - e.R4LES));
+    const T foeewi = rexp<T>(e.R3IES * (tt - e.RTT) / (tt - e.R4IES));
+    T qs;
+    if constexpr (MODE == 0) {
+        const T alfa = foealfa(e, tt);
+        const T foeew = alfa * (e.R2ES * foeewl) + (T(1.0) - alfa) * (e.R2ES * foeewi);
+        qs = rmin<T>(foeew / ap[i], e.QMAX);
+    } else {
+        const T alfa = (MODE == 1) ? foealfcu(e, tt) : foealfa(e, tt);
+        const T ew = e.R2ES * (alfa * foeewl + (T(1.0) - alfa) * foeewi);
+        qs = rmin<T>(ew / ap[i], e.QMAX);
+    }
+    qsat[i] = qs / (T(1.0) - e.RETV * qs);
+}
+
+template <typename T>
+int launch_saturation(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* ap, const T* t,
+                      T* qsat, hipStream_t stream) {
+    const Ext<T> e = make_ext<T>(p);
+    const dim3 grid((nx + kAuxBlock - 1) / kAuxBlock, nz), block(kAuxBlock);
+    if (p.LPHYLIN)
+        hipLaunchKernelGGL((saturation_kernel<T, 0>), grid, block, 0, stream, e, nx, ls, ap, t, qsat);
+    else if (p.KFLAG == 1)
+        hipLaunchKernelGGL((saturation_kernel<T, 1>), grid, block, 0, stream, e, nx, ls, ap, t, qsat);
+    else
+        hipLaunchKernelGGL((saturation_kernel<T, 2>), grid, block, 0, stream, e, nx, ls, ap, t, qsat);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kAuxBlock)
+increment_kernel(int nx, int64_t ls, CPtrs<T, INC_NUM> in, MPtrs<T, INC_NUM> out, T f, int ignore_supsat) {
+    const int col = blockIdx.x * kAuxBlock + threadIdx.x;
+    if (col >= nx) return;
+    const int64_t i = int64_t(blockIdx.y) * ls + col;
+    T v[INC_NUM];
+#pragma unroll
+    for (int n = 0; n < INC_NUM; ++n) v[n] = in.p[n][i];
+#pragma unroll
+    for (int n = 0; n < INC_NUM; ++n) {
+        T r = f * v[n];
+        if (n == INC_SUPSAT && ignore_supsat) r = T(0.0);
+        out.p[n][i] = r;
+    }
+}
+
+template <typename T>
+int launch_increment(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* const* in,
+                     T* const* out, double f, hipStream_t stream) {
+    CPtrs<T, INC_NUM> ci;
+    MPtrs<T, INC_NUM> co;
+    for (int i = 0; i < INC_NUM; ++i) { ci.p[i] = in[i]; co.p[i] = out[i]; }
+    const dim3 grid((nx + kAuxBlock - 1) / kAuxBlock, nz + 1), block(kAuxBlock);
+    hipLaunchKernelGGL((increment_kernel<T>), grid, block, 0, stream, nx, ls, ci, co, static_cast<T>(f),
+                       int(p.IGNORE_SUPSAT));
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kAuxBlock)
+perturb_kernel(int nx, int64_t ls, CPtrs<T, INC_NUM> in, CPtrs<T, INC_NUM> in_i, MPtrs<T, INC_NUM> out, T f) {
+    const int col = blockIdx.x * kAuxBlock + threadIdx.x;
+    if (col >= nx) return;
+    const int64_t i = int64_t(blockIdx.y) * ls + col;
+    T a[INC_NUM], b[INC_NUM];
+#pragma unroll
+    for (int n = 0; n < INC_NUM; ++n) { a[n] = in.p[n][i]; b[n] = in_i.p[n][i]; }
+#pragma unroll
+    for (int n = 0; n < INC_NUM; ++n) out.p[n][i] = a[n] + f * b[n];
+}
+
+template <typename T>
+int launch_perturb(int nx, int nz, int64_t ls, const T* const* in, const T* const* in_i, T* const* out,
+                   double f, hipStream_t stream) {
+    CPtrs<T, INC_NUM> ci, cii;
+    MPtrs<T, INC_NUM> co;
+    for (int i = 0; i < INC_NUM; ++i) { ci.p[i] = in[i]; cii.p[i] = in_i[i]; co.p[i] = out[i]; }
+    const dim3 grid((nx + kAuxBlock - 1) / kAuxBlock, nz + 1), block(kAuxBlock);
+    hipLaunchKernelGGL((perturb_kernel<T>), grid, block, 0, stream, nx, ls, ci, cii, co, static_cast<T>(f));
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+#define CS2_INST(T)                                                                                           \
+    template int launch_saturation<T>(const Cloudsc2Params&, int, int, int64_t, const T*, const T*, T*,      \
+                                      hipStream_t);                                                           \
+    template int launch_increment<T>(const Cloudsc2Params&, int, int, int64_t, const T* const*, T* const*,   \
+                                     double, hipStream_t);                                                    \
+    template int launch_perturb<T>(int, int, int64_t, const T* const*, const T* const*, T* const*, double,   \
+                                   hipStream_t);
+CS2_INST(double)
+CS2_INST(float)
+#undef CS2_INST
+
+}  // namespace cs2

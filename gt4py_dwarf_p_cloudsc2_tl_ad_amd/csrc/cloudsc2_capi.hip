@@ -1,0 +1,207 @@
+// extern "C" boundary of libcloudsc2_hip.so - see include/cloudsc2_hip.h for the contract.
+// Argument checking happens here (on the host, before anything is launched): a kernel is only
+// launched when the shapes it assumes hold, because a faulting kernel can take the whole node down.
+#include <cstdarg>
+#include <cstdio>
+
+#include "cloudsc2_common.hpp"
+
+namespace cs2 {
+template <typename T>
+int launch_nl(const Cloudsc2Params&, int, int, int64_t, const T* const*, const T*, T* const*, double, hipStream_t);
+template <typename T>
+int launch_tl(const Cloudsc2Params&, int, int, int64_t, const T* const*, const T* const*, const T*, T* const*,
+              T* const*, double, hipStream_t);
+template <typename T>
+int launch_ad(const Cloudsc2Params&, int, int, int64_t, const T* const*, const T* const*, const T*, T* const*,
+              T* const*, double, hipStream_t);
+template <typename T>
+int launch_saturation(const Cloudsc2Params&, int, int, int64_t, const T*, const T*, T*, hipStream_t);
+template <typename T>
+int launch_increment(const Cloudsc2Params&, int, int, int64_t, const T* const*, T* const*, double, hipStream_t);
+template <typename T>
+int launch_perturb(int, int, int64_t, const T* const*, const T* const*, T* const*, double, hipStream_t);
+}  // namespace cs2
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+constexpr int kMaxLevels = 4096;  // LDS table: 2 * (nz+1) * 8 B must stay well below 64 KiB
+
+int check_common(const char* fn, const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls) {
+    if (!p) return fail(CLOUDSC2_E_ARG, "%s: params is NULL", fn);
+    if (nx < 0) return fail(CLOUDSC2_E_ARG, "%s: nx=%d < 0", fn, nx);
+    if (nz < 2 || nz > kMaxLevels) return fail(CLOUDSC2_E_ARG, "%s: nz=%d outside [2, %d]", fn, nz, kMaxLevels);
+    if (ls < nx) return fail(CLOUDSC2_E_ARG, "%s: lev_stride=%lld < nx=%d", fn, (long long)ls, nx);
+    return 0;
+}
+
+template <typename T>
+int check_ptrs(const char* fn, const char* what, const T* const* arr, int n) {
+    if (!arr) return fail(CLOUDSC2_E_ARG, "%s: %s is NULL", fn, what);
+    for (int i = 0; i < n; ++i)
+        if (!arr[i]) return fail(CLOUDSC2_E_ARG, "%s: %s[%d] is NULL", fn, what, i);
+    return 0;
+}
+
+int launched(const char* fn, int rc) {
+    if (rc == 0) return CLOUDSC2_OK;
+    return fail(CLOUDSC2_E_LAUNCH, "%s: HIP launch failed: %s", fn, hipGetErrorString(hipPeekAtLastError()));
+}
+
+template <typename T>
+int nl_impl(const char* fn, const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls, const T* const* in,
+            const T* eta, T* const* out, double dt, void* stream) {
+    if (int rc = check_common(fn, p, nx, nz, ls)) return rc;
+    if (int rc = check_ptrs(fn, "in", in, NL_NUM_IN)) return rc;
+    if (int rc = check_ptrs(fn, "out", const_cast<const T* const*>(out), NL_NUM_OUT)) return rc;
+    if (!eta) return fail(CLOUDSC2_E_ARG, "%s: eta is NULL", fn);
+    if (p->ICALL != 0) return fail(CLOUDSC2_E_UNSUPPORTED, "%s: ICALL=%d (the reference implements ICALL == 0 only)", fn, p->ICALL);
+    if (!(dt > 0.0)) return fail(CLOUDSC2_E_ARG, "%s: dt=%g must be > 0", fn, dt);
+    if (nx == 0) return CLOUDSC2_OK;
+    return launched(fn, cs2::launch_nl<T>(*p, nx, nz, ls, in, eta, out, dt, static_cast<hipStream_t>(stream)));
+}
+
+template <typename T>
+int tl_impl(const char* fn, const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls, const T* const* in,
+            const T* const* in_i, const T* eta, T* const* out, T* const* out_i, double dt, void* stream) {
+    if (int rc = check_common(fn, p, nx, nz, ls)) return rc;
+    if (int rc = check_ptrs(fn, "in", in, NL_NUM_IN)) return rc;
+    if (int rc = check_ptrs(fn, "in_i", in_i, NL_NUM_IN)) return rc;
+    if (int rc = check_ptrs(fn, "out", const_cast<const T* const*>(out), NL_NUM_OUT)) return rc;
+    if (int rc = check_ptrs(fn, "out_i", const_cast<const T* const*>(out_i), NL_NUM_OUT)) return rc;
+    if (!eta) return fail(CLOUDSC2_E_ARG, "%s: eta is NULL", fn);
+    if (p->ICALL != 0) return fail(CLOUDSC2_E_UNSUPPORTED, "%s: ICALL=%d unsupported", fn, p->ICALL);
+    if (!(dt > 0.0)) return fail(CLOUDSC2_E_ARG, "%s: dt=%g must be > 0", fn, dt);
+    if (p->NLEV != nz) return fail(CLOUDSC2_E_ARG, "%s: NLEV=%d != nz=%d", fn, p->NLEV, nz);
+    if (nx == 0) return CLOUDSC2_OK;
+    return launched(fn, cs2::launch_tl<T>(*p, nx, nz, ls, in, in_i, eta, out, out_i, dt, static_cast<hipStream_t>(stream)));
+}
+
+template <typename T>
+int ad_impl(const char* fn, const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls, const T* const* in,
+            const T* const* in_adj, const T* eta, T* const* out, T* const* out_adj, double dt, void* stream) {
+    if (int rc = check_common(fn, p, nx, nz, ls)) return rc;
+    if (int rc = check_ptrs(fn, "in", in, NL_NUM_IN)) return rc;
+    if (int rc = check_ptrs(fn, "in_adj", in_adj, NL_NUM_OUT)) return rc;
+    if (int rc = check_ptrs(fn, "out", const_cast<const T* const*>(out), NL_NUM_OUT)) return rc;
+    if (int rc = check_ptrs(fn, "out_adj", const_cast<const T* const*>(out_adj), NL_NUM_IN)) return rc;
+    if (!eta) return fail(CLOUDSC2_E_ARG, "%s: eta is NULL", fn);
+    if (p->ICALL != 0) return fail(CLOUDSC2_E_UNSUPPORTED, "%s: ICALL=%d unsupported", fn, p->ICALL);
+    if (!(dt > 0.0)) return fail(CLOUDSC2_E_ARG, "%s: dt=%g must be > 0", fn, dt);
+    if (p->NLEV != nz) return fail(CLOUDSC2_E_ARG, "%s: NLEV=%d != nz=%d", fn, p->NLEV, nz);
+    if (nx == 0) return CLOUDSC2_OK;
+    return launched(fn, cs2::launch_ad<T>(*p, nx, nz, ls, in, in_adj, eta, out, out_adj, dt, static_cast<hipStream_t>(stream)));
+}
+
+template <typename T>
+int sat_impl(const char* fn, const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls, const T* ap, const T* t,
+             T* qsat, void* stream) {
+    if (int rc = check_common(fn, p, nx, nz, ls)) return rc;
+    if (!ap || !t || !qsat) return fail(CLOUDSC2_E_ARG, "%s: NULL field pointer", fn);
+    if (nx == 0) return CLOUDSC2_OK;
+    return launched(fn, cs2::launch_saturation<T>(*p, nx, nz, ls, ap, t, qsat, static_cast<hipStream_t>(stream)));
+}
+
+template <typename T>
+int inc_impl(const char* fn, const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls, const T* const* in,
+             T* const* out, double f, void* stream) {
+    if (int rc = check_common(fn, p, nx, nz, ls)) return rc;
+    if (int rc = check_ptrs(fn, "in", in, INC_NUM)) return rc;
+    if (int rc = check_ptrs(fn, "out_i", const_cast<const T* const*>(out), INC_NUM)) return rc;
+    if (nx == 0) return CLOUDSC2_OK;
+    return launched(fn, cs2::launch_increment<T>(*p, nx, nz, ls, in, out, f, static_cast<hipStream_t>(stream)));
+}
+
+template <typename T>
+int per_impl(const char* fn, const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls, const T* const* in,
+             const T* const* in_i, T* const* out, double f, void* stream) {
+    if (int rc = check_common(fn, p, nx, nz, ls)) return rc;
+    if (int rc = check_ptrs(fn, "in", in, INC_NUM)) return rc;
+    if (int rc = check_ptrs(fn, "in_i", in_i, INC_NUM)) return rc;
+    if (int rc = check_ptrs(fn, "out", const_cast<const T* const*>(out), INC_NUM)) return rc;
+    if (nx == 0) return CLOUDSC2_OK;
+    return launched(fn, cs2::launch_perturb<T>(nx, nz, ls, in, in_i, out, f, static_cast<hipStream_t>(stream)));
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t cloudsc2_abi_version(void) { return CLOUDSC2_ABI_VERSION; }
+int32_t cloudsc2_params_sizeof(void) { return (int32_t)sizeof(Cloudsc2Params); }
+const char* cloudsc2_last_error(void) { return g_err; }
+int32_t cloudsc2_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int32_t cloudsc2_nl_f64(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls, const double* const* in,
+                        const double* eta, double* const* out, double dt, void* stream) {
+    return nl_impl<double>("cloudsc2_nl_f64", p, nx, nz, ls, in, eta, out, dt, stream);
+}
+int32_t cloudsc2_nl_f32(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls, const float* const* in,
+                        const float* eta, float* const* out, double dt, void* stream) {
+    return nl_impl<float>("cloudsc2_nl_f32", p, nx, nz, ls, in, eta, out, dt, stream);
+}
+int32_t cloudsc2_tl_f64(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls, const double* const* in,
+                        const double* const* in_i, const double* eta, double* const* out, double* const* out_i,
+                        double dt, void* stream) {
+    return tl_impl<double>("cloudsc2_tl_f64", p, nx, nz, ls, in, in_i, eta, out, out_i, dt, stream);
+}
+int32_t cloudsc2_tl_f32(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls, const float* const* in,
+                        const float* const* in_i, const float* eta, float* const* out, float* const* out_i,
+                        double dt, void* stream) {
+    return tl_impl<float>("cloudsc2_tl_f32", p, nx, nz, ls, in, in_i, eta, out, out_i, dt, stream);
+}
+int32_t cloudsc2_ad_f64(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls, const double* const* in,
+                        const double* const* in_adj, const double* eta, double* const* out,
+                        double* const* out_adj, double dt, void* stream) {
+    return ad_impl<double>("cloudsc2_ad_f64", p, nx, nz, ls, in, in_adj, eta, out, out_adj, dt, stream);
+}
+int32_t cloudsc2_ad_f32(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls, const float* const* in,
+                        const float* const* in_adj, const float* eta, float* const* out, float* const* out_adj,
+                        double dt, void* stream) {
+    return ad_impl<float>("cloudsc2_ad_f32", p, nx, nz, ls, in, in_adj, eta, out, out_adj, dt, stream);
+}
+int32_t cloudsc2_saturation_f64(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls, const double* ap,
+                                const double* t, double* qsat, void* stream) {
+    return sat_impl<double>("cloudsc2_saturation_f64", p, nx, nz, ls, ap, t, qsat, stream);
+}
+int32_t cloudsc2_saturation_f32(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls, const float* ap,
+                                const float* t, float* qsat, void* stream) {
+    return sat_impl<float>("cloudsc2_saturation_f32", p, nx, nz, ls, ap, t, qsat, stream);
+}
+int32_t cloudsc2_state_increment_f64(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls,
+                                     const double* const* in, double* const* out_i, double f, void* stream) {
+    return inc_impl<double>("cloudsc2_state_increment_f64", p, nx, nz, ls, in, out_i, f, stream);
+}
+int32_t cloudsc2_state_increment_f32(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls,
+                                     const float* const* in, float* const* out_i, double f, void* stream) {
+    return inc_impl<float>("cloudsc2_state_increment_f32", p, nx, nz, ls, in, out_i, f, stream);
+}
+int32_t cloudsc2_perturbed_state_f64(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls,
+                                     const double* const* in, const double* const* in_i, double* const* out,
+                                     double f, void* stream) {
+    return per_impl<double>("cloudsc2_perturbed_state_f64", p, nx, nz, ls, in, in_i, out, f, stream);
+}
+int32_t cloudsc2_perturbed_state_f32(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls,
+                                     const float* const* in, const float* const* in_i, float* const* out,
+                                     double f, void* stream) {
+    return per_impl<float>("cloudsc2_perturbed_state_f32", p, nx, nz, ls, in, in_i, out, f, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,151 @@
+// Shared device-side definitions for the CLOUDSC2 HIP kernels (gfx950 / CDNA4 only).
+//
+// Execution model used by every column kernel in this directory:
+//   * one lane = one atmospheric column, one wave64 = 64 adjacent columns, workgroup = 1 wave;
+//   * fields are [level][column], so every per-level access of a wave is one fully coalesced
+//     512-B (fp64) / 256-B (fp32) request;
+//   * the vertical loop is sequential per lane; the loop-carried precipitation state lives in
+//     registers, level-only quantities (eta, scalm) live in a small LDS table built per workgroup.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/cloudsc2_hip.h"
+
+namespace cs2 {
+
+constexpr int kWave = 64;  // CDNA wavefront
+
+// ---- math in the working precision --------------------------------------------------------
+template <typename T> __device__ __forceinline__ T rexp(T x);
+template <> __device__ __forceinline__ double rexp<double>(double x) { return exp(x); }
+template <> __device__ __forceinline__ float rexp<float>(float x) { return expf(x); }
+template <typename T> __device__ __forceinline__ T rtanh(T x);
+template <> __device__ __forceinline__ double rtanh<double>(double x) { return tanh(x); }
+template <> __device__ __forceinline__ float rtanh<float>(float x) { return tanhf(x); }
+template <typename T> __device__ __forceinline__ T rcosh(T x);
+template <> __device__ __forceinline__ double rcosh<double>(double x) { return cosh(x); }
+template <> __device__ __forceinline__ float rcosh<float>(float x) { return coshf(x); }
+template <typename T> __device__ __forceinline__ T rsqrt_(T x);
+template <> __device__ __forceinline__ double rsqrt_<double>(double x) { return sqrt(x); }
+template <> __device__ __forceinline__ float rsqrt_<float>(float x) { return sqrtf(x); }
+template <typename T> __device__ __forceinline__ T rpow(T x, T y);
+template <> __device__ __forceinline__ double rpow<double>(double x, double y) { return pow(x, y); }
+template <> __device__ __forceinline__ float rpow<float>(float x, float y) { return powf(x, y); }
+template <typename T> __device__ __forceinline__ T rmin(T a, T b) { return a < b ? a : b; }
+template <typename T> __device__ __forceinline__ T rmax(T a, T b) { return a > b ? a : b; }
+template <typename T> __device__ __forceinline__ T sq(T x) { return x * x; }
+template <typename T> __device__ __forceinline__ T cube(T x) { return x * x * x; }
+
+// ---- externals in the working precision -----------------------------------------------------
+template <typename T>
+struct Ext {
+    T R2ES, R3IES, R3LES, R4IES, R4LES, R5IES, R5LES;
+    T R5ALSCP, R5ALVCP, RALSDCP, RALVDCP;
+    T RTICE, RTWAT, RTWAT_RTICE_R, RTICECU, RTWAT_RTICECU_R, RVTMP2;
+    T RCPD, RD, RETV, RG, RLMLT, RLSTT, RLVTT, RTT;
+    T RCLCRIT, RKCONV, RLMIN, RPECONS, RLPTRC;
+    T ZEPS1, ZEPS2, ZQMAX, ZSCAL, QMAX;
+    int32_t NLEV;
+};
+
+template <typename T>
+inline Ext<T> make_ext(const Cloudsc2Params& p) {
+    Ext<T> e;
+#define CS2_CP(n) e.n = static_cast<T>(p.n)
+    CS2_CP(R2ES); CS2_CP(R3IES); CS2_CP(R3LES); CS2_CP(R4IES); CS2_CP(R4LES); CS2_CP(R5IES); CS2_CP(R5LES);
+    CS2_CP(R5ALSCP); CS2_CP(R5ALVCP); CS2_CP(RALSDCP); CS2_CP(RALVDCP);
+    CS2_CP(RTICE); CS2_CP(RTWAT); CS2_CP(RTWAT_RTICE_R); CS2_CP(RTICECU); CS2_CP(RTWAT_RTICECU_R); CS2_CP(RVTMP2);
+    CS2_CP(RCPD); CS2_CP(RD); CS2_CP(RETV); CS2_CP(RG); CS2_CP(RLMLT); CS2_CP(RLSTT); CS2_CP(RLVTT); CS2_CP(RTT);
+    CS2_CP(RCLCRIT); CS2_CP(RKCONV); CS2_CP(RLMIN); CS2_CP(RPECONS); CS2_CP(RLPTRC);
+    CS2_CP(ZEPS1); CS2_CP(ZEPS2); CS2_CP(ZQMAX); CS2_CP(ZSCAL); CS2_CP(QMAX);
+#undef CS2_CP
+    e.NLEV = p.NLEV;
+    return e;
+}
+
+// ---- field pointer bundles (kernel arguments, by value) --------------------------------------
+template <typename T, int N>
+struct CPtrs { const T* p[N]; };
+template <typename T, int N>
+struct MPtrs { T* p[N]; };
+
+// Per-level LDS table: eta[k] and scalm[k] = ZSCAL * max(eta[k]-0.2, ZEPS1)^0.2
+// (nonlinear/_stencils/cloudsc2.py:127).  `pow` is evaluated once per level per workgroup instead
+// of once per level per column.  Also returns the tropopause search window [klo, khi]: the levels
+// k in [0, nz-2] with 0.1 < eta[k] < 0.4 (cloudsc2.py:109-110); klo > khi when the window is empty.
+template <typename T>
+__device__ __forceinline__ void build_level_table(const T* __restrict__ eta, int nz, const Ext<T>& e,
+                                                  T* s_eta, T* s_scalm, int& klo, int& khi) {
+    for (int k = threadIdx.x; k <= nz; k += blockDim.x) {
+        T ek = eta[k];
+        s_eta[k] = ek;
+        s_scalm[k] = e.ZSCAL * rpow<T>(rmax<T>(ek - T(0.2), e.ZEPS1), T(0.2));
+    }
+    __syncthreads();
+    klo = nz;
+    khi = -1;
+    for (int k = 0; k < nz - 1; ++k) {
+        T ek = s_eta[k];
+        if (ek > T(0.1) && ek < T(0.4)) {
+            if (k < klo) klo = k;
+            khi = k;
+        }
+    }
+}
+
+// Critical relative humidity profile (nonlinear/_stencils/cloudsc2.py:166-186); rh2/deta1 depend on
+// the column's tropopause eta only and are hoisted out of the level loop by the callers.
+template <typename T>
+struct CrhCol { T trpaus, rh2, bound1, deta1, bound2; };
+
+template <typename T>
+__device__ __forceinline__ CrhCol<T> crh_setup(T trpaus) {
+    CrhCol<T> c;
+    c.trpaus = trpaus;
+    c.rh2 = T(0.35) + T(0.14) * sq((trpaus - T(0.25)) / T(0.15)) +
+            T(0.04) * rmin<T>(trpaus - T(0.25), T(0.0)) / T(0.15);
+    c.bound1 = trpaus + T(0.3);
+    c.deta1 = T(0.09) + T(0.16) * (T(0.4) - trpaus) / T(0.3);
+    c.bound2 = T(1.0) - c.deta1;
+    return c;
+}
+
+template <typename T>
+__device__ __forceinline__ T crh2_at(const CrhCol<T>& c, T eta) {
+    const T rh1 = T(1.0), rh3 = T(1.0);
+    if (eta < c.trpaus) return rh3;
+    if (eta < c.bound1) return rh3 + (c.rh2 - rh3) * (eta - c.trpaus) / T(0.3);
+    if (eta < c.bound2) return c.rh2;
+    return rh1 + (c.rh2 - rh1) * rsqrt_<T>((T(1.0) - eta) / c.deta1);
+}
+
+// One iteration of the saturation adjustment (nonlinear/_stencils/cuadjtqs.py:24-37).
+template <typename T>
+__device__ __forceinline__ void cuadjtqs_nl_0(const Ext<T>& e, T ap, T& t, T& q, T z3es, T z4es,
+                                              T z5alcp, T zaldcp) {
+    T foeew = e.R2ES * rexp<T>(z3es * (t - e.RTT) / (t - z4es));
+    T qsat = rmin<T>(foeew / ap, e.ZQMAX);
+    T cor = T(1.0) / (T(1.0) - e.RETV * qsat);
+    qsat *= cor;
+    T z2s = z5alcp / sq(t - z4es);
+    T cond = (q - qsat) / (T(1.0) + qsat * cor * z2s);
+    t += zaldcp * cond;
+    q -= cond;
+}
+
+// nonlinear/_stencils/cuadjtqs.py:40-68 (ICALL == 0, the only branch the reference implements).
+template <typename T>
+__device__ __forceinline__ void cuadjtqs_nl(const Ext<T>& e, T ap, T& t, T& q) {
+    T z3es, z4es, z5alcp, zaldcp;
+    if (t > e.RTT) {
+        z3es = e.R3LES; z4es = e.R4LES; z5alcp = e.R5ALVCP; zaldcp = e.RALVDCP;
+    } else {
+        z3es = e.R3IES; z4es = e.R4IES; z5alcp = e.R5ALSCP; zaldcp = e.RALSDCP;
+    }
+    cuadjtqs_nl_0(e, ap, t, q, z3es, z4es, z5alcp, zaldcp);
+    cuadjtqs_nl_0(e, ap, t, q, z3es, z4es, z5alcp, zaldcp);
+}
+
+}  // namespace cs2

@@ -1,0 +1,294 @@
+"""Stencil objects of the MI355X build: the counterpart of what the reference obtains from
+``self.compile_stencil(name, externals)`` (nonlinear/microphysics.py:79, tangent_linear/microphysics.py:92,
+adjoint/microphysics.py:89, common/saturation.py:54, common/increment.py:47-49,146 under
+/root/reference/src/cloudsc2_gt4py/physics/).
+
+A stencil object is called exactly like a GT4Py `StencilObject`: keyword field arguments named as
+in the gtscript signature, then ``dt=`` (or ``f=``), ``origin=``, ``domain=``, ``validate_args=``,
+``exec_info=``; it returns ``None`` and writes its outputs in place.  Each call is one launch of a
+hand-written gfx950 kernel through the C ABI of libcloudsc2_hip.so.  There is no CPU path: without
+the library (or without a GPU) the call raises.
+
+Error behaviour mirrors GT4Py's: argument problems found with ``validate_args=True`` raise
+`ValueError` / `TypeError` before anything is launched; launch failures raise `RuntimeError`.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Any, Callable, Dict, Mapping, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from .params import make_params
+from .storage import field_geometry
+
+# gtscript parameter names in C-ABI order (include/cloudsc2_hip.h enums)
+NL_IN = ("ap", "aph", "lu", "lude", "mfd", "mfu", "q", "qi", "ql", "qsat", "supsat", "t",
+         "tnd_cml_q", "tnd_cml_qi", "tnd_cml_ql", "tnd_cml_t")
+NL_OUT = ("clc", "covptot", "fhpsl", "fhpsn", "fplsl", "fplsn", "tnd_q", "tnd_qi", "tnd_ql", "tnd_t")
+INC = ("aph", "ap", "q", "qsat", "t", "ql", "qi", "lude", "lu", "mfu", "mfd",
+       "tnd_cml_t", "tnd_cml_q", "tnd_cml_ql", "tnd_cml_qi", "supsat")
+
+_SFX = {torch.float64: "f64", torch.float32: "f32"}
+
+#: scratch / bookkeeping arguments of the gtscript signatures that the native kernels keep in
+#: registers (accepted for call compatibility, never touched)
+_IGNORED_PREFIX = "tmp_"
+
+
+def _current_stream_ptr(device: torch.device) -> int:
+    return int(torch.cuda.current_stream(device).cuda_stream)
+
+
+class HipStencil:
+    """Base of the callable stencil objects."""
+
+    name: str = ""
+    scalar_name: str = "dt"
+    nlev_offset: int = 1  # domain[2] = nz + nlev_offset
+
+    def __init__(self, externals: Mapping[str, Any]):
+        self.externals = dict(externals)
+        self.params = make_params(self.externals)
+        self._lib = _lib.load()  # raises if the HIP library is missing: no fallback
+
+    # -- argument handling ---------------------------------------------------------------
+    def _field_names(self) -> Sequence[str]:
+        raise NotImplementedError
+
+    def _geometry(self, fields: Mapping[str, torch.Tensor], domain, origin, validate: bool):
+        first = next(iter(fields.values()))
+        nx, nlev, ls = field_geometry(first)
+        nz = nlev - 1
+        if origin is not None and tuple(origin) != (0, 0, 0):
+            raise ValueError(f"{self.name}: only origin=(0, 0, 0) is supported, got {tuple(origin)}")
+        if domain is not None:
+            d = tuple(int(x) for x in domain)
+            if d != (nx, 1, nz + self.nlev_offset):
+                raise ValueError(
+                    f"{self.name}: domain {d} does not match the storages "
+                    f"(expected {(nx, 1, nz + self.nlev_offset)})"
+                )
+        if validate:
+            dev, dt = first.device, first.dtype
+            if dev.type != "cuda":
+                raise ValueError(f"{self.name}: fields must live on the GPU, got device {dev}")
+            if dt not in _SFX:
+                raise TypeError(f"{self.name}: unsupported dtype {dt}")
+            for n, f in fields.items():
+                if not isinstance(f, torch.Tensor):
+                    raise TypeError(f"{self.name}: argument {n} is not a torch.Tensor")
+                if f.device != dev or f.dtype != dt:
+                    raise TypeError(f"{self.name}: argument {n} has device/dtype {f.device}/{f.dtype}, "
+                                    f"expected {dev}/{dt}")
+                g = field_geometry(f)
+                if g != (nx, nlev, ls):
+                    raise ValueError(f"{self.name}: argument {n} has (nx, nlev, lev_stride) = {g}, "
+                                     f"expected {(nx, nlev, ls)}")
+        return nx, nz, ls, first.dtype, first.device
+
+    def _collect(self, kwargs: Dict[str, Any]) -> Dict[str, torch.Tensor]:
+        fields = {}
+        for n in self._field_names():
+            if n not in kwargs:
+                raise TypeError(f"{self.name}: missing field argument '{n}'")
+            fields[n] = kwargs.pop(n)
+        for n in list(kwargs):
+            if n.startswith(_IGNORED_PREFIX):
+                kwargs.pop(n)
+        return fields
+
+    def _kvec(self, v: Any, nz: int, dtype, device, validate: bool) -> torch.Tensor:
+        if validate:
+            if not isinstance(v, torch.Tensor) or v.dim() != 1 or v.shape[0] < nz + 1:
+                raise ValueError(f"{self.name}: in_eta must be a 1-D tensor with >= {nz + 1} entries")
+            if v.dtype != dtype or v.device != device or not v.is_contiguous():
+                raise TypeError(f"{self.name}: in_eta must be contiguous {dtype} on {device}")
+        return v
+
+    def __call__(self, **kwargs: Any) -> None:
+        origin = kwargs.pop("origin", None)
+        domain = kwargs.pop("domain", None)
+        validate = bool(kwargs.pop("validate_args", True))
+        exec_info: Optional[dict] = kwargs.pop("exec_info", None)
+        scalar = 0.0
+        if self.scalar_name:
+            if self.scalar_name not in kwargs:
+                raise TypeError(f"{self.name}: missing scalar argument '{self.scalar_name}'")
+            scalar = float(kwargs.pop(self.scalar_name))
+        eta = kwargs.pop("in_eta", None)
+        fields = self._collect(kwargs)
+        if kwargs:
+            raise TypeError(f"{self.name}: unexpected arguments {sorted(kwargs)}")
+        nx, nz, ls, dtype, device = self._geometry(fields, domain, origin, validate)
+        if eta is not None:
+            eta = self._kvec(eta, nz, dtype, device, validate)
+        ev = None
+        if exec_info is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        with torch.cuda.device(device):
+            rc = self._launch(fields, eta, scalar, nx, nz, ls, _SFX[dtype], _current_stream_ptr(device))
+        _lib.check(rc, self.name)
+        if ev is not None:
+            ev[1].record()
+            rec = exec_info.setdefault(self.name, {"ncalls": 0, "events": []})
+            rec["ncalls"] += 1
+            rec["events"].append(ev)
+
+    def _launch(self, fields, eta, scalar, nx, nz, ls, sfx, stream) -> int:
+        raise NotImplementedError
+
+    def _fn(self, base: str, sfx: str) -> Callable:
+        return getattr(self._lib, f"cloudsc2_{base}_{sfx}")
+
+
+def _ptrs(fields: Mapping[str, torch.Tensor], names: Sequence[str]):
+    return _lib.ptr_array([fields[n].data_ptr() for n in names])
+
+
+class Cloudsc2NLStencil(HipStencil):
+    """`cloudsc2_nl` - nonlinear/_stencils/cloudsc2.py:24-60 (signature), :93-399 (body)."""
+
+    name = "cloudsc2_nl"
+
+    def _field_names(self):
+        return tuple("in_" + n for n in NL_IN) + tuple("out_" + n for n in NL_OUT)
+
+    def _launch(self, fields, eta, scalar, nx, nz, ls, sfx, stream):
+        if eta is None:
+            raise TypeError("cloudsc2_nl: missing field argument 'in_eta'")
+        return self._fn("nl", sfx)(
+            ctypes.byref(self.params), nx, nz, ls,
+            _ptrs(fields, ["in_" + n for n in NL_IN]), eta.data_ptr(),
+            _ptrs(fields, ["out_" + n for n in NL_OUT]), scalar, stream)
+
+
+class Cloudsc2TLStencil(HipStencil):
+    """`cloudsc2_tl` - tangent_linear/_stencils/cloudsc2.py:23-90 (signature), :124-774 (body)."""
+
+    name = "cloudsc2_tl"
+
+    def _field_names(self):
+        return (tuple("in_" + n for n in NL_IN) + tuple("in_" + n + "_i" for n in NL_IN)
+                + tuple("out_" + n for n in NL_OUT) + tuple("out_" + n + "_i" for n in NL_OUT))
+
+    def _launch(self, fields, eta, scalar, nx, nz, ls, sfx, stream):
+        if eta is None:
+            raise TypeError("cloudsc2_tl: missing field argument 'in_eta'")
+        self.params.NLEV = nz
+        return self._fn("tl", sfx)(
+            ctypes.byref(self.params), nx, nz, ls,
+            _ptrs(fields, ["in_" + n for n in NL_IN]), _ptrs(fields, ["in_" + n + "_i" for n in NL_IN]),
+            eta.data_ptr(),
+            _ptrs(fields, ["out_" + n for n in NL_OUT]), _ptrs(fields, ["out_" + n + "_i" for n in NL_OUT]),
+            scalar, stream)
+
+
+class Cloudsc2ADStencil(HipStencil):
+    """`cloudsc2_ad` - adjoint/_stencils/cloudsc2.py:24-90 (signature), :124-996 (body)."""
+
+    name = "cloudsc2_ad"
+
+    def _field_names(self):
+        return (tuple("in_" + n for n in NL_IN) + tuple("in_" + n + "_i" for n in NL_OUT)
+                + tuple("out_" + n for n in NL_OUT) + tuple("out_" + n + "_i" for n in NL_IN))
+
+    def _launch(self, fields, eta, scalar, nx, nz, ls, sfx, stream):
+        if eta is None:
+            raise TypeError("cloudsc2_ad: missing field argument 'in_eta'")
+        self.params.NLEV = nz
+        return self._fn("ad", sfx)(
+            ctypes.byref(self.params), nx, nz, ls,
+            _ptrs(fields, ["in_" + n for n in NL_IN]), _ptrs(fields, ["in_" + n + "_i" for n in NL_OUT]),
+            eta.data_ptr(),
+            _ptrs(fields, ["out_" + n for n in NL_OUT]), _ptrs(fields, ["out_" + n + "_i" for n in NL_IN]),
+            scalar, stream)
+
+
+class SaturationStencil(HipStencil):
+    """`saturation` - common/_stencils/saturation.py:23-42; domain (nx, 1, nz)."""
+
+    name = "saturation"
+    scalar_name = ""
+    nlev_offset = 0
+
+    def _field_names(self):
+        return ("in_ap", "in_t", "out_qsat")
+
+    def _launch(self, fields, eta, scalar, nx, nz, ls, sfx, stream):
+        return self._fn("saturation", sfx)(
+            ctypes.byref(self.params), nx, nz, ls,
+            fields["in_ap"].data_ptr(), fields["in_t"].data_ptr(), fields["out_qsat"].data_ptr(), stream)
+
+
+class StateIncrementStencil(HipStencil):
+    """`state_increment` - common/_stencils/state_increment.py:22-80."""
+
+    name = "state_increment"
+    scalar_name = "f"
+
+    def _field_names(self):
+        return tuple("in_" + n for n in INC) + tuple("out_" + n + "_i" for n in INC)
+
+    def _launch(self, fields, eta, scalar, nx, nz, ls, sfx, stream):
+        return self._fn("state_increment", sfx)(
+            ctypes.byref(self.params), nx, nz, ls,
+            _ptrs(fields, ["in_" + n for n in INC]), _ptrs(fields, ["out_" + n + "_i" for n in INC]),
+            scalar, stream)
+
+
+class PerturbedStateStencil(HipStencil):
+    """`perturbed_state` - common/_stencils/perturbed_state.py:22-91."""
+
+    name = "perturbed_state"
+    scalar_name = "f"
+
+    def _field_names(self):
+        return (tuple("in_" + n for n in INC) + tuple("in_" + n + "_i" for n in INC)
+                + tuple("out_" + n for n in INC))
+
+    def _launch(self, fields, eta, scalar, nx, nz, ls, sfx, stream):
+        return self._fn("perturbed_state", sfx)(
+            ctypes.byref(self.params), nx, nz, ls,
+            _ptrs(fields, ["in_" + n for n in INC]), _ptrs(fields, ["in_" + n + "_i" for n in INC]),
+            _ptrs(fields, ["out_" + n for n in INC]), scalar, stream)
+
+
+#: registry keyed by the names the reference registers with `@stencil_collection(name)`
+STENCILS: Dict[str, type] = {
+    "cloudsc2_nl": Cloudsc2NLStencil,
+    "cloudsc2_tl": Cloudsc2TLStencil,
+    "cloudsc2_ad": Cloudsc2ADStencil,
+    "saturation": SaturationStencil,
+    "state_increment": StateIncrementStencil,
+    "perturbed_state": PerturbedStateStencil,
+}
+
+
+def compile_stencil(name: str, externals: Optional[Mapping[str, Any]] = None) -> HipStencil:
+    """Counterpart of the components' ``self.compile_stencil(name, externals)``.
+
+    Nothing is compiled at run time: the externals select a prebuilt kernel instantiation
+    (boolean switches) and fill the `Cloudsc2Params` struct (numeric values); unknown externals are
+    ignored, as GT4Py ignores externals a stencil does not import."""
+    try:
+        cls = STENCILS[name]
+    except KeyError:
+        raise KeyError(f"unknown stencil '{name}'; available: {sorted(STENCILS)}") from None
+    return cls(externals or {})
+
+
+def finalize_exec_info(exec_info: Optional[dict]) -> None:
+    """Resolve the recorded HIP events into `total_run_time` (seconds) per stencil."""
+    if not exec_info:
+        return
+    torch.cuda.synchronize()
+    for rec in exec_info.values():
+        if isinstance(rec, dict) and "events" in rec:
+            tot = rec.get("total_run_time", 0.0)
+            for a, b in rec["events"]:
+                tot += a.elapsed_time(b) * 1e-3
+            rec["total_run_time"] = tot
+            rec["events"] = []

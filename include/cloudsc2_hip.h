@@ -1,0 +1,134 @@
+/*
+ * cloudsc2_hip.h - C ABI of the MI355X-native CLOUDSC2 column-physics engine (libcloudsc2_hip.so).
+ *
+ * Each entry point replaces ONE GT4Py stencil object of the reference, i.e. the callable that
+ * `compile_stencil(name, externals)` returns and that the components invoke with keyword field
+ * arguments (`self.cloudsc2(in_ap=..., ..., dt=..., origin=(0,0,0), domain=(nx,1,nz+1), ...)`).
+ * The reference call sites are cited per function below (paths relative to
+ * /root/reference/src/cloudsc2_gt4py/physics/).
+ *
+ * Conventions shared by every entry point
+ *   - plain C types only; no torch / HIP types in the signatures (`stream` is a hipStream_t
+ *     passed as void*, NULL = the legacy default stream);
+ *   - all field pointers are DEVICE pointers (HBM) owned by the caller; the library never
+ *     allocates, frees or copies fields;
+ *   - field layout is [level][column]: element (column c, level k) of a field lives at
+ *     ptr[k * lev_stride + c], 0 <= c < nx, 0 <= k <= nz (every field has nz+1 levels, as every
+ *     reference storage has, nonlinear/microphysics.py:168-169; the padding level nz of a
+ *     full-level field is never written and, for `lu`, must be 0, nonlinear/_stencils/cloudsc2.py:212);
+ *   - `eta` is a device vector of nz+1 values (`in_eta`, gtscript.Field[K]);
+ *   - pointer-array arguments (`in`, `out`) are HOST arrays of device pointers in the order of
+ *     the enum documented with the function (= the order of the gtscript signature);
+ *   - the boolean externals LPHYLIN / LDRAIN1D / LEVAPLS2 / LREGCL / IGNORE_SUPSAT select a kernel
+ *     instantiation, the numeric externals travel by value in `Cloudsc2Params`;
+ *   - return value: 0 on success, <0 on error (CLOUDSC2_E_*); `cloudsc2_last_error()` returns a
+ *     thread-local message.  Kernels are launched asynchronously on `stream`.
+ */
+#ifndef CLOUDSC2_HIP_H
+#define CLOUDSC2_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CLOUDSC2_ABI_VERSION 1
+
+#define CLOUDSC2_OK 0
+#define CLOUDSC2_E_ARG (-1)      /* bad argument (null pointer, nx/nz/stride out of range)      */
+#define CLOUDSC2_E_UNSUPPORTED (-2) /* externals combination that has no kernel instantiation  */
+#define CLOUDSC2_E_LAUNCH (-3)   /* HIP reported an error at launch                              */
+#define CLOUDSC2_E_NODEVICE (-4) /* no HIP device visible                                        */
+
+/* Numeric + boolean externals (names = /root/reference/src/cloudsc2_gt4py/iox.py:25-209 and the
+ * literals of nonlinear/microphysics.py:68-78, common/saturation.py:51, common/increment.py:47-49).
+ * Mirrored field-for-field by `Cloudsc2Params` in gt4py_dwarf_p_cloudsc2_tl_ad_amd/params.py. */
+typedef struct Cloudsc2Params {
+    double R2ES, R3IES, R3LES, R4IES, R4LES, R5IES, R5LES;
+    double R5ALSCP, R5ALVCP, RALSDCP, RALVDCP;
+    double RTICE, RTWAT, RTWAT_RTICE_R, RTICECU, RTWAT_RTICECU_R, RVTMP2;
+    double RCPD, RD, RETV, RG, RLMLT, RLSTT, RLVTT, RTT;
+    double RCLCRIT, RKCONV, RLMIN, RPECONS, RLPTRC;
+    double ZEPS1, ZEPS2, ZQMAX, ZSCAL, QMAX;
+    int32_t LPHYLIN, LDRAIN1D, LEVAPLS2, LREGCL, ICALL, KFLAG, IGNORE_SUPSAT, NLEV;
+} Cloudsc2Params;
+
+int32_t cloudsc2_abi_version(void);
+int32_t cloudsc2_params_sizeof(void);
+const char* cloudsc2_last_error(void);
+/* number of HIP devices visible to the library's runtime (0 if none / runtime unusable) */
+int32_t cloudsc2_device_count(void);
+
+/* ---- cloudsc2_nl : nonlinear/_stencils/cloudsc2.py:24-399, called at nonlinear/microphysics.py:134-172 */
+enum { /* order of `in` */
+    NL_IN_AP, NL_IN_APH, NL_IN_LU, NL_IN_LUDE, NL_IN_MFD, NL_IN_MFU, NL_IN_Q, NL_IN_QI, NL_IN_QL,
+    NL_IN_QSAT, NL_IN_SUPSAT, NL_IN_T, NL_IN_TND_CML_Q, NL_IN_TND_CML_QI, NL_IN_TND_CML_QL,
+    NL_IN_TND_CML_T, NL_NUM_IN
+};
+enum { /* order of `out` */
+    NL_OUT_CLC, NL_OUT_COVPTOT, NL_OUT_FHPSL, NL_OUT_FHPSN, NL_OUT_FPLSL, NL_OUT_FPLSN,
+    NL_OUT_TND_Q, NL_OUT_TND_QI, NL_OUT_TND_QL, NL_OUT_TND_T, NL_NUM_OUT
+};
+int32_t cloudsc2_nl_f64(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t lev_stride,
+                        const double* const* in, const double* eta, double* const* out, double dt,
+                        void* stream);
+int32_t cloudsc2_nl_f32(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t lev_stride,
+                        const float* const* in, const float* eta, float* const* out, double dt,
+                        void* stream);
+
+/* ---- saturation : common/_stencils/saturation.py:23-42, called at common/saturation.py:67-76
+ * (domain nx x 1 x nz: level nz of out_qsat is not written) */
+int32_t cloudsc2_saturation_f64(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t lev_stride,
+                                const double* ap, const double* t, double* qsat, void* stream);
+int32_t cloudsc2_saturation_f32(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t lev_stride,
+                                const float* ap, const float* t, float* qsat, void* stream);
+
+/* ---- state_increment : common/_stencils/state_increment.py:22-80, called at common/increment.py:93-132
+ * ---- perturbed_state : common/_stencils/perturbed_state.py:22-91, called at common/increment.py:219-261
+ * Field order of the 16-entry arrays (same for in / in_i / out): */
+enum {
+    INC_APH, INC_AP, INC_Q, INC_QSAT, INC_T, INC_QL, INC_QI, INC_LUDE, INC_LU, INC_MFU, INC_MFD,
+    INC_TND_CML_T, INC_TND_CML_Q, INC_TND_CML_QL, INC_TND_CML_QI, INC_SUPSAT, INC_NUM
+};
+int32_t cloudsc2_state_increment_f64(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t lev_stride,
+                                     const double* const* in, double* const* out_i, double f, void* stream);
+int32_t cloudsc2_state_increment_f32(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t lev_stride,
+                                     const float* const* in, float* const* out_i, double f, void* stream);
+int32_t cloudsc2_perturbed_state_f64(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t lev_stride,
+                                     const double* const* in, const double* const* in_i,
+                                     double* const* out, double f, void* stream);
+int32_t cloudsc2_perturbed_state_f32(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t lev_stride,
+                                     const float* const* in, const float* const* in_i,
+                                     float* const* out, double f, void* stream);
+
+/* ---- cloudsc2_tl : tangent_linear/_stencils/cloudsc2.py:23-774, called at tangent_linear/microphysics.py:162-242
+ * `in` / `in_i`: the 16 NL inputs and their perturbations, NL_IN_* order;
+ * `out` / `out_i`: the 10 NL outputs and their perturbations, NL_OUT_* order. */
+int32_t cloudsc2_tl_f64(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t lev_stride,
+                        const double* const* in, const double* const* in_i, const double* eta,
+                        double* const* out, double* const* out_i, double dt, void* stream);
+int32_t cloudsc2_tl_f32(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t lev_stride,
+                        const float* const* in, const float* const* in_i, const float* eta,
+                        float* const* out, float* const* out_i, double dt, void* stream);
+
+/* ---- cloudsc2_ad : adjoint/_stencils/cloudsc2.py:24-996, called at adjoint/microphysics.py:159-238
+ * `in`     : the 16 NL inputs (trajectory), NL_IN_* order;
+ * `in_adj` : adjoint forcing = perturbations of the 10 NL outputs, NL_OUT_* order
+ *            (in_clc_i, in_covptot_i, in_fhpsl_i, in_fhpsn_i, in_fplsl_i, in_fplsn_i,
+ *             in_tnd_q_i, in_tnd_qi_i, in_tnd_ql_i, in_tnd_t_i); NOT modified (the reference
+ *            zeroes them in place, adjoint/_stencils/cloudsc2.py:481-484 ...; nothing reads them
+ *            afterwards);
+ * `out`    : the 10 NL outputs recomputed along the trajectory, NL_OUT_* order;
+ * `out_adj`: adjoint of the 16 inputs, NL_IN_* order (out_ap_i ... out_tnd_cml_t_i). */
+int32_t cloudsc2_ad_f64(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t lev_stride,
+                        const double* const* in, const double* const* in_adj, const double* eta,
+                        double* const* out, double* const* out_adj, double dt, void* stream);
+int32_t cloudsc2_ad_f32(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t lev_stride,
+                        const float* const* in, const float* const* in_adj, const float* eta,
+                        float* const* out, float* const* out_adj, double dt, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLOUDSC2_HIP_H */

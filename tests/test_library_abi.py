@@ -1,0 +1,80 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads and exports every
+symbol include/cloudsc2_hip.h declares; argument validation rejects bad calls before any launch."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_are_exported(hip_lib):
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd import _lib
+
+    header = open(os.path.join(ROOT, "include", "cloudsc2_hip.h")).read()
+    declared = set(re.findall(r"\b(cloudsc2_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
+    for s in declared:
+        assert hasattr(hip_lib, s), s
+
+
+def test_params_struct_matches(hip_lib):
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.params import ABI_VERSION, Cloudsc2Params
+
+    assert hip_lib.cloudsc2_abi_version() == ABI_VERSION
+    assert hip_lib.cloudsc2_params_sizeof() == ctypes.sizeof(Cloudsc2Params)
+    header = open(os.path.join(ROOT, "include", "cloudsc2_hip.h")).read()
+    body = header[header.index("typedef struct Cloudsc2Params {"):header.index("} Cloudsc2Params;")]
+    names = []
+    for line in body.splitlines()[1:]:
+        line = line.split("/*")[0].strip().rstrip(";")
+        if line.startswith(("double", "int32_t")):
+            names += [n.strip() for n in line.split(None, 1)[1].split(",")]
+    assert names == [n for n, _ in Cloudsc2Params._fields_]
+
+
+def test_bad_arguments_are_rejected_without_launch(hip_lib):
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd import _lib
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.params import default_externals, make_params
+
+    p = make_params(default_externals())
+    null = _lib.ptr_array([0] * 16)
+    nullo = _lib.ptr_array([0] * 10)
+    rc = hip_lib.cloudsc2_nl_f64(ctypes.byref(p), 64, 137, 64, null, 0, nullo, 3600.0, None)
+    assert rc == -1 and "NULL" in _lib.last_error()
+    rc = hip_lib.cloudsc2_nl_f64(ctypes.byref(p), -5, 137, 64, null, 0, nullo, 3600.0, None)
+    assert rc == -1 and "nx" in _lib.last_error()
+    rc = hip_lib.cloudsc2_nl_f64(ctypes.byref(p), 64, 137, 32, null, 0, nullo, 3600.0, None)
+    assert rc == -1 and "lev_stride" in _lib.last_error()
+    with pytest.raises(ValueError):
+        _lib.check(rc, "cloudsc2_nl")
+
+
+def test_missing_library_is_loud(monkeypatch, tmp_path):
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd import _lib
+
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.Cloudsc2LibraryError):
+        _lib.load()
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.stencils import compile_stencil
+
+    with pytest.raises(_lib.Cloudsc2LibraryError):
+        compile_stencil("cloudsc2_nl", {})
+
+
+def test_stencil_rejects_cpu_tensors(hip_lib):
+    import torch
+
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd import storage
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.stencils import compile_stencil
+
+    st = compile_stencil("saturation", {})
+    a = storage.zeros(8, 4, torch.float64, "cpu")
+    with pytest.raises(ValueError, match="GPU"):
+        st(in_ap=a, in_t=a, out_qsat=a, origin=(0, 0, 0), domain=(8, 1, 4), validate_args=True, exec_info=None)
+    with pytest.raises(ValueError, match="domain"):
+        st(in_ap=a, in_t=a, out_qsat=a, origin=(0, 0, 0), domain=(8, 1, 5), validate_args=True, exec_info=None)
+    with pytest.raises(KeyError):
+        compile_stencil("no_such_stencil", {})

@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Headline benchmark: CLOUDSC2-NL fp64, 65 536 columns x 137 levels per GPU (BASELINE.json configs[1]).
+
+One "step" = the reference driver's timed region (/root/reference/drivers/run_nonlinear.py:115-119):
+`saturation(state)` followed by `cloudsc2_nl(state, dt)` on the same resident state, i.e. two kernel
+launches through the C ABI of libcloudsc2_hip.so.  Inputs are synthetic columns generated directly
+in HBM (gt4py_dwarf_p_cloudsc2_tl_ad_amd/synthetic.py; the reference's data/input.h5 is not
+available) and are resident before the timed region starts.
+
+  python bench.py --gpus 1 --steps 50 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU, every rank owns `--cols` columns of a global N*cols-column problem
+(weak scaling; columns are independent, so there is NO data-path collective).  RCCL is used only
+for the barrier / max-over-ranks timing and for the final validation-norm all-reduce.
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (`nl_kernel`): algorithmic bytes
+per launch (28 536 B/column fp64) / the kernel's mean duration measured with HIP
+events on the launch stream.  `cpu_baseline` times the NumPy oracle (1 core) on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+NL_WORDS_PER_COL = 3567          # 15*137 + 138 read, 6*137 + 4*138 written
+SAT_WORDS_PER_COL = 411          # 2 in, 1 out over 137 levels
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--cols", type=int, default=65536, help="columns per GPU")
+    ap.add_argument("--nlev", type=int, default=137)
+    ap.add_argument("--precision", choices=["double", "single"], default="double")
+    ap.add_argument("--cpu-cols", type=int, default=16384,
+                    help="columns of the CPU-baseline sample (0 disables the baseline)")
+    ap.add_argument("--no-roofline-events", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(cols: int, nz: int, np_dtype):
+    """Oracle (NumPy restatement, the GT4Py-numpy-like execution shape) on the host: saturation + NL
+    on `cols` synthetic columns, one timed run after one small warm-up."""
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import externals, nl_case, run_oracle_nl
+    from oracle import cloudsc2_numpy as oracle
+
+    ext = externals()
+    run_oracle_nl(*nl_case(64, nz, np_dtype), ext)  # warm-up (imports, allocator)
+    fields, eta, dt = nl_case(cols, nz, np_dtype)
+    t0 = time.perf_counter()
+    oracle.saturation(fields["in_ap"], fields["in_t"], fields["in_qsat"], ext)
+    run_oracle_nl(fields, eta, dt, ext)
+    el = time.perf_counter() - t0
+    return {
+        "value": cols / el,
+        "unit": "columns/s",
+        "cores": 1,
+        "host_cores": os.cpu_count(),
+        "kind": "port",
+        "sample": f"NumPy oracle (oracle/cloudsc2_numpy.py), saturation + cloudsc2_nl, {cols} cols x {nz} lev "
+                  f"{np.dtype(np_dtype).name}, 1 run, {el:.2f} s, synthetic-parameters",
+    }
+
+
+def main():
+    args = parse_args()
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+
+    import __graft_entry__ as ge
+
+    ge.build()
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd import storage
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.params import DEFAULT_TIMESTEP_S, default_externals
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.stencils import NL_OUT, compile_stencil
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.synthetic import eta_levels, make_state
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=device)
+
+    np_dtype = np.float64 if args.precision == "double" else np.float32
+    wsize = np.dtype(np_dtype).itemsize
+    nx, nz = args.cols, args.nlev
+    total = nx * world
+    ext = default_externals()
+    dt = DEFAULT_TIMESTEP_S
+
+    # resident state: this rank's slice [rank*nx, (rank+1)*nx) of the global problem
+    s = make_state(total, nz, col0=rank * nx, ncols=nx, dtype=np_dtype, device=device)
+    eta = torch.as_tensor(eta_levels(nz, dtype=np_dtype), device=device)  # from GLOBAL column 0
+    f = {k: storage.logical_view(v) for k, v in s.items()}
+    qsat = storage.zeros(nx, nz, np_dtype, device)
+    ins = {"in_" + k[2:]: v for k, v in f.items()}
+    ins["in_qsat"] = qsat
+    outs = {"out_" + n: storage.zeros(nx, nz, np_dtype, device) for n in NL_OUT}
+    sat = compile_stencil("saturation", ext)
+    nl = compile_stencil("cloudsc2_nl", ext)
+
+    def step():
+        sat(in_ap=f["f_ap"], in_t=f["f_t"], out_qsat=qsat, origin=(0, 0, 0), domain=(nx, 1, nz),
+            validate_args=False, exec_info=None)
+        nl(**ins, **outs, in_eta=eta, dt=dt, origin=(0, 0, 0), domain=(nx, 1, nz + 1),
+           validate_args=False, exec_info=None)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # dominant-kernel duration: HIP events on the launch stream around each cloudsc2_nl launch
+    nl_ms = None
+    if not args.no_roofline_events:
+        evs = []
+        for _ in range(max(5, min(args.steps, 50))):
+            sat(in_ap=f["f_ap"], in_t=f["f_t"], out_qsat=qsat, origin=(0, 0, 0), domain=(nx, 1, nz),
+                validate_args=False, exec_info=None)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            nl(**ins, **outs, in_eta=eta, dt=dt, origin=(0, 0, 0), domain=(nx, 1, nz + 1),
+               validate_args=False, exec_info=None)
+            b.record()
+            evs.append((a, b))
+        torch.cuda.synchronize()
+        times = sorted(a.elapsed_time(b) for a, b in evs)
+        nl_ms = sum(times) / len(times)
+
+    # validation norm (the only data reduction across ranks): sum of every NL output
+    norm = torch.stack([storage.klayout(outs["out_" + n]).double().abs().sum() for n in NL_OUT])
+    finite = all(bool(torch.isfinite(storage.klayout(v)[: nz]).all()) for v in outs.values())
+    if dist is not None:
+        dist.all_reduce(norm, op=dist.ReduceOp.SUM)
+    norm = [float(x) for x in norm.cpu()]
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = total * args.steps / elapsed
+        res = {
+            "metric": "columns/sec at 137 levels fp64; achieved HBM GB/s vs MI355X roofline",
+            "value": value,
+            "unit": "columns/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64" if args.precision == "double" else "f32",
+            "data": "synthetic columns + synthetic-parameters (reference data/input.h5 unavailable)",
+            "config": {
+                "workload": f"CLOUDSC2-NL (saturation + cloudsc2_nl), {nx} cols x {nz} lev per GPU, "
+                            f"{args.precision}, {world} GPU(s), {total} columns total",
+                "columns_per_gpu": nx, "levels": nz, "timestep_s": dt,
+                "parallelism": f"column-sharded x{world}, no data-path collective",
+            },
+            "outputs_finite": finite,
+            "validation_norm": dict(zip(NL_OUT, norm)),
+        }
+        if nl_ms is not None:
+            nl_bytes = NL_WORDS_PER_COL * wsize * nx
+            achieved = nl_bytes / (nl_ms * 1e-3) / 1e9
+            res["roofline"] = {
+                "kernel": "cs2::nl_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "bytes_per_launch": nl_bytes, "avg_launch_ms": nl_ms,
+                "kernel_columns_per_s": nx / (nl_ms * 1e-3),
+            }
+        if world == 1 and args.cpu_cols > 0:
+            res["cpu_baseline"] = cpu_baseline(args.cpu_cols, nz, np_dtype)
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,9 +1,812 @@
-// placeholder until the ad kernel lands (same round); the C-ABI reports CLOUDSC2_E_LAUNCH.
+// cloudsc2_ad as a hand-written CDNA4 kernel.  Restates
+// /root/reference/src/cloudsc2_gt4py/physics/adjoint/_stencils/cloudsc2.py:124-996 and
+// /root/reference/src/cloudsc2_gt4py/physics/adjoint/_stencils/cuadjtqs.py:22-158
+// (line numbers below refer to the first file unless prefixed "cuadjtqs").
+//
+// GT4Py keeps ~80 trajectory temporaries of the forward computation as full 3-D fields for the
+// backward computation.  Here NOTHING but the stencil's own outputs goes to HBM:
+//   sweep 1 (k = 0 .. nz-1)  recomputes the NL trajectory and writes the 10 NL outputs (:146-475);
+//   sweep 2 (k = nz-1 .. 0)  re-reads level k's 16 state inputs + the snow flux that entered the
+//                            level (= out_fplsn[k], written by sweep 1 of the same lane), recomputes
+//                            that level's local trajectory in registers and runs the adjoint
+//                            statements (:479-996) on it.
+// The only loop-carried trajectory values are the fluxes entering a level, and those are outputs.
+// Backward carries: tmp_rfln_i, tmp_sfln_i, rfl_i/sfl_i of the level below, and daph_i/dp_i/dlu_i of
+// the level below for the staggered corrections (:970-986), which are fused into the sweep.
+//
+// Deliberate, documented choices:
+//   Q1  adjoint forcings (in_*_i) are read-only here; the reference zeroes them in place.
+//   Q8  rfl_i / sfl_i of a level that does not melt read as 0 (unassigned GT4Py temporaries).
+//   out_lude_i is written (=), not accumulated into prior storage contents (:526 uses -= on an
+//       output the stencil never initialises; zero-initialised storage gives the same result).
+//   Q4/Q5 are reproduced literally when FIX = false (the reference's behaviour): the second
+//       freezing test uses the pre-adjustment t3 (:427, :577) and the adjoint of rfreeze1 tests the
+//       post-adjustment t (:729).  FIX = true (Cloudsc2Params.AD_TRAJ_FIX, a build extension) uses
+//       the tests of the NL/TL stencils instead, which makes AD the exact transpose of TL.
+// Template flags: REG = LREGCL.  The evaporation block (:357-394, :635-709) is not instantiated.
 #include "cloudsc2_common.hpp"
+
 namespace cs2 {
+
 template <typename T>
-int launch_ad(const Cloudsc2Params&, int, int, int64_t, const T* const*, const T* const*, const T*, T* const*,
-              T* const*, double, hipStream_t) { return -1; }
-template int launch_ad<double>(const Cloudsc2Params&, int, int, int64_t, const double* const*, const double* const*, const double*, double* const*, double* const*, double, hipStream_t);
-template int launch_ad<float>(const Cloudsc2Params&, int, int, int64_t, const float* const*, const float* const*, const float*, float* const*, float* const*, double, hipStream_t);
+struct ADIn {
+    T ap, aph1, lu1, lude, mfd, mfu, q, qi, ql, qsat, supsat, t, tq, tqi, tql, tt;
+};
+
+template <typename T>
+__device__ __forceinline__ ADIn<T> ad_load(const CPtrs<T, NL_NUM_IN>& in, int64_t ls, int col, int k) {
+    const int64_t o = int64_t(k) * ls + col;
+    ADIn<T> x;
+    x.ap = in.p[NL_IN_AP][o];
+    x.aph1 = in.p[NL_IN_APH][o + ls];
+    x.lu1 = in.p[NL_IN_LU][o + ls];
+    x.lude = in.p[NL_IN_LUDE][o];
+    x.mfd = in.p[NL_IN_MFD][o];
+    x.mfu = in.p[NL_IN_MFU][o];
+    x.q = in.p[NL_IN_Q][o];
+    x.qi = in.p[NL_IN_QI][o];
+    x.ql = in.p[NL_IN_QL][o];
+    x.qsat = in.p[NL_IN_QSAT][o];
+    x.supsat = in.p[NL_IN_SUPSAT][o];
+    x.t = in.p[NL_IN_T][o];
+    x.tq = in.p[NL_IN_TND_CML_Q][o];
+    x.tqi = in.p[NL_IN_TND_CML_QI][o];
+    x.tql = in.p[NL_IN_TND_CML_QL][o];
+    x.tt = in.p[NL_IN_TND_CML_T][o];
+    return x;
 }
+
+// Saved state of the two saturation-adjustment iterations (cuadjtqs:53-91).
+template <typename T>
+struct CuadjSav {
+    T z4es, z5alcp, zaldcp, dfo;  // dfo = z3es * (RTT - z4es)
+    T foeew_b, qsat_d, targ_b, qsat_b, cor_b, z2s_b, q_b;
+    T foeew_a, qsat_c, targ_a, qsat_a, cor_a, z2s_a, q_a;
+    bool ltest2, ltest1;
+};
+
+template <typename T>
+__device__ __forceinline__ void cuadj_fwd_save(const Ext<T>& e, T ap, T& t, T& q, CuadjSav<T>& s) {
+    T z3es;
+    if (t > e.RTT) {
+        z3es = e.R3LES; s.z4es = e.R4LES; s.z5alcp = e.R5ALVCP; s.zaldcp = e.RALVDCP;
+    } else {
+        z3es = e.R3IES; s.z4es = e.R4IES; s.z5alcp = e.R5ALSCP; s.zaldcp = e.RALSDCP;
+    }
+    s.dfo = z3es * (e.RTT - s.z4es);
+    {
+        const T foeew = e.R2ES * rexp<T>(z3es * (t - e.RTT) / (t - s.z4es));
+        s.foeew_b = foeew;
+        T qsat = foeew / ap;
+        s.ltest2 = qsat > e.ZQMAX;
+        if (s.ltest2) qsat = e.ZQMAX;
+        const T cor = T(1.0) / (T(1.0) - e.RETV * qsat);
+        s.qsat_d = qsat;
+        qsat *= cor;
+        s.targ_b = t;
+        const T z2s = s.z5alcp / sq(t - s.z4es);
+        s.qsat_b = qsat; s.cor_b = cor; s.z2s_b = z2s; s.q_b = q;
+        const T cond1 = (q - qsat) / (T(1.0) + qsat * cor * z2s);
+        t += s.zaldcp * cond1;
+        q -= cond1;
+    }
+    {
+        const T foeew = e.R2ES * rexp<T>(z3es * (t - e.RTT) / (t - s.z4es));
+        s.foeew_a = foeew;
+        T qsat = foeew / ap;
+        s.ltest1 = qsat > e.ZQMAX;
+        if (s.ltest1) qsat = e.ZQMAX;
+        const T cor = T(1.0) / (T(1.0) - e.RETV * qsat);
+        s.qsat_c = qsat;
+        qsat *= cor;
+        s.targ_a = t;
+        const T z2s = s.z5alcp / sq(t - s.z4es);
+        s.qsat_a = qsat; s.cor_a = cor; s.z2s_a = z2s; s.q_a = q;
+        const T cond1 = (q - qsat) / (T(1.0) + qsat * cor * z2s);
+        t += s.zaldcp * cond1;
+        q -= cond1;
+    }
+}
+
+// Reverse of one iteration (cuadjtqs:93-124 / :126-156); returns this iteration's qp_i contribution.
+template <typename T>
+__device__ __forceinline__ T cuadj_bwd_iter(const Ext<T>& e, const CuadjSav<T>& s, T ap, T& t_i, T& q_i, T qsat,
+                                            T cor, T z2s, T q_sav, T targ, T qsat_pre, bool ltest, T foeew) {
+    const T cond1_i = -q_i + s.zaldcp * t_i;
+    const T den = T(1.0) + qsat * cor * z2s;
+    q_i += cond1_i / den;
+    T qsat_i = -cond1_i / den - cond1_i * (q_sav - qsat) * cor * z2s / sq(den);
+    T cor_i = -cond1_i * (q_sav - qsat) * qsat * z2s / sq(den);
+    const T z2s_i = -cond1_i * (q_sav - qsat) * qsat * cor / sq(den);
+    T targ_i = T(-2.0) * z2s_i * s.z5alcp / cube(targ - s.z4es);
+    cor_i += qsat_i * qsat_pre;
+    qsat_i *= cor;
+    qsat_i += cor_i * e.RETV / sq(T(1.0) - e.RETV * qsat_pre);
+    if (ltest) qsat_i = T(0.0);
+    const T foeew_i = qsat_i / ap;
+    const T qp_i = qsat_i * foeew;
+    // R2ES * exp(z3es (targ - RTT) / (targ - z4es)) is the saved foeew (cuadjtqs:117-122)
+    targ_i += foeew_i * foeew * s.dfo / sq(targ - s.z4es);
+    t_i += targ_i;
+    return qp_i;
+}
+
+template <typename T>
+__device__ __forceinline__ void cuadj_bwd(const Ext<T>& e, const CuadjSav<T>& s, T ap, T& ap_i, T& t_i, T& q_i) {
+    T qp_i = cuadj_bwd_iter(e, s, ap, t_i, q_i, s.qsat_a, s.cor_a, s.z2s_a, s.q_a, s.targ_a, s.qsat_c, s.ltest1,
+                            s.foeew_a);
+    qp_i += cuadj_bwd_iter(e, s, ap, t_i, q_i, s.qsat_b, s.cor_b, s.z2s_b, s.q_b, s.targ_b, s.qsat_d, s.ltest2,
+                           s.foeew_b);
+    ap_i -= qp_i / sq(ap);
+}
+
+// Local trajectory of one level (:149-458), everything the backward statements read.
+template <typename T>
+struct ADTraj {
+    T t2, q2, ql, qi, dp, lfdcp, lsdcp, lvdcp, fwat, foeew, esdp1, facw, faci, fac, cor, dqsdtemp;
+    T crh2, supsat, qsat, qcrit, qt, qcd, qpd, tmp3, clc, gdp, lude, out_clc;
+    T fac1, rho, fac2, rodqsdp, ldcp, fac3, dtdzmo, dqsdz, fac4, dqc, qc3;
+    T qlwc1, qiwc1, condl1, condi1, cons, z2s, snmlt;
+    T cldl, ltmp1, ltmp2, prr, cldi, itmp11, itmp12, itmp2, prs;
+    T rfreeze1, fwatr1, t3, qold, dq, dr2, fwatr2, condl2, condi2, rfreeze3;
+    T t_post, q_post, rfln, sfln, tnd_q, tnd_t, tnd_ql, tnd_qi;
+    bool lo1, lo3, melt, cloudy, t3_cold, tpost_cold;
+    int cls;  // 0 clear (qt <= qcrit), 1 overcast, 2 partial
+    CuadjSav<T> adj;
+};
+
+template <typename T, bool FIX>
+__device__ __forceinline__ void ad_forward(const Ext<T>& e, const ADIn<T>& x, T aph_k, int k, T eta_k, T scalm,
+                                           const CrhCol<T>& crh, T dt, T rfl, T sfl, ADTraj<T>& r) {
+    const T ckcodtl = T(2.0) * e.RKCONV * dt;
+    const T ckcodti = T(5.0) * e.RKCONV * dt;
+    const T cons2 = T(1.0) / (e.RG * dt);
+    const T meltp2 = e.RTT + T(2.0);
+    // :135-137, :153-157
+    T t = x.t + dt * x.tt;
+    r.t2 = t;
+    T q = x.q + dt * x.tq + x.supsat;
+    r.ql = x.ql + dt * x.tql;
+    r.qi = x.qi + dt * x.tqi;
+    r.q2 = q;
+    // :170-174
+    r.dp = x.aph1 - aph_k;
+    const T zz = e.RCPD + e.RCPD * e.RVTMP2 * q;
+    r.lfdcp = e.RLMLT / zz;
+    r.lsdcp = e.RLSTT / zz;
+    r.lvdcp = e.RLVTT / zz;
+    // :181-197
+    T z3es, z4es;
+    if (t < e.RTT) {
+        r.fwat = T(0.545) * (rtanh<T>(T(0.17) * (r.t2 - e.RLPTRC)) + T(1.0));
+        z3es = e.R3IES;
+        z4es = e.R4IES;
+    } else {
+        r.fwat = T(1.0);
+        z3es = e.R3LES;
+        z4es = e.R4LES;
+    }
+    r.foeew = e.R2ES * rexp<T>(z3es * (r.t2 - e.RTT) / (r.t2 - z4es));
+    r.esdp1 = r.foeew / x.ap;
+    const T esdp = rmin<T>(r.esdp1, e.ZQMAX);
+    r.facw = e.R5LES / sq(r.t2 - e.R4LES);
+    r.faci = e.R5IES / sq(r.t2 - e.R4IES);
+    r.fac = r.fwat * r.facw + (T(1.0) - r.fwat) * r.faci;
+    r.cor = T(1.0) / (T(1.0) - e.RETV * esdp);
+    r.dqsdtemp = r.fac * r.cor * x.qsat;
+    // :203-231
+    r.crh2 = crh2_at(crh, eta_k);
+    r.supsat = (r.t2 < e.RTICE) ? T(1.8) - T(0.003) * r.t2 : T(1.0);
+    r.qsat = x.qsat * r.supsat;
+    r.qcrit = r.crh2 * r.qsat;
+    // :234-252
+    r.qt = q + r.ql + r.qi;
+    T qc1;
+    if (r.qt <= r.qcrit) {
+        r.cls = 0;
+        r.clc = T(0.0);
+        qc1 = T(0.0);
+        r.qcd = T(0.0);
+        r.qpd = T(0.0);
+        r.tmp3 = T(0.0);
+    } else if (r.qt >= r.qsat) {
+        r.cls = 1;
+        r.clc = T(1.0);
+        qc1 = (T(1.0) - scalm) * (r.qsat - r.qcrit);
+        r.qcd = T(0.0);
+        r.qpd = T(0.0);
+        r.tmp3 = T(0.0);
+    } else {
+        r.cls = 2;
+        r.qcd = r.qsat - r.qcrit;
+        r.qpd = r.qsat - r.qt;
+        r.tmp3 = rsqrt_<T>(r.qpd / (r.qcd - scalm * (r.qt - r.qcrit)));
+        r.clc = T(1.0) - r.tmp3;
+        qc1 = (scalm * r.qpd + (T(1.0) - scalm) * r.qcd) * sq(r.clc);
+    }
+    // :255-263
+    r.gdp = e.RG / (x.aph1 - aph_k);
+    r.lude = dt * x.lude * r.gdp;
+    r.lo1 = r.lude >= e.RLMIN && x.lu1 >= e.ZEPS2;
+    T qc2;
+    if (r.lo1) {
+        r.out_clc = r.clc + (T(1.0) - r.clc) * (T(1.0) - rexp<T>(-r.lude / x.lu1));
+        qc2 = qc1 + r.lude;
+    } else {
+        r.out_clc = r.clc;
+        qc2 = qc1;
+    }
+    // :266-277
+    r.fac1 = T(1.0) / (e.RD * r.t2);
+    r.rho = x.ap * r.fac1;
+    r.fac2 = T(1.0) / (x.ap - e.RETV * r.foeew);
+    r.rodqsdp = -r.rho * x.qsat * r.fac2;
+    r.ldcp = r.fwat * r.lvdcp + (T(1.0) - r.fwat) * r.lsdcp;
+    r.fac3 = T(1.0) / (T(1.0) + r.ldcp * r.dqsdtemp);
+    r.dtdzmo = e.RG * (T(1.0) / e.RCPD - r.ldcp * r.rodqsdp) * r.fac3;
+    r.dqsdz = r.dqsdtemp * r.dtdzmo - e.RG * r.rodqsdp;
+    r.fac4 = T(1.0) / r.rho;
+    const T sub = dt * r.dqsdz * (x.mfu + x.mfd) * r.fac4;
+    r.lo3 = sub < qc2;
+    r.dqc = rmin<T>(sub, qc2);
+    r.qc3 = qc2 - r.dqc;
+    // :280-283
+    r.qlwc1 = r.qc3 * r.fwat;
+    r.qiwc1 = r.qc3 * (T(1.0) - r.fwat);
+    r.condl1 = (r.qlwc1 - r.ql) / dt;
+    r.condi1 = (r.qiwc1 - r.qi) / dt;
+    // :293-302 melting of incoming snow
+    r.melt = sfl != T(0.0);
+    T rfln, sfln;
+    if (r.melt) {
+        r.cons = cons2 * r.dp / r.lfdcp;
+        r.z2s = r.cons * rmax<T>(r.t2 - meltp2, T(0.0));
+        r.snmlt = rmin<T>(sfl, r.z2s);
+        rfln = rfl + r.snmlt;
+        sfln = sfl - r.snmlt;
+        t = r.t2 - r.snmlt / r.cons;
+    } else {
+        r.cons = T(1.0);
+        r.z2s = T(0.0);
+        r.snmlt = T(0.0);
+        rfln = rfl;
+        sfln = sfl;
+    }
+    // :305-337 autoconversion
+    r.cloudy = r.out_clc > e.ZEPS2;
+    T qlwc = r.qlwc1, qiwc = r.qiwc1;
+    if (r.cloudy) {
+        const T lcrit = T(2.0) * e.RCLCRIT;
+        r.cldl = r.qlwc1 / r.out_clc;
+        r.ltmp1 = rexp<T>(-sq(r.cldl / lcrit));
+        const T dl = ckcodtl * (T(1.0) - r.ltmp1);
+        r.ltmp2 = rexp<T>(-dl);
+        const T qlnew = r.out_clc * r.cldl * r.ltmp2;
+        r.prr = r.qlwc1 - qlnew;
+        qlwc = r.qlwc1 - r.prr;
+        const T icrit = T(2.0) * e.RCLCRIT;
+        r.cldi = r.qiwc1 / r.out_clc;
+        r.itmp11 = rexp<T>(-sq(r.cldi / icrit));
+        r.itmp12 = rexp<T>(T(0.025) * (t - e.RTT));
+        const T di = ckcodti * r.itmp12 * (T(1.0) - r.itmp11);
+        r.itmp2 = rexp<T>(-di);
+        const T qinew = r.out_clc * r.cldi * r.itmp2;
+        r.prs = r.qiwc1 - qinew;
+        qiwc = r.qiwc1 - r.prs;
+    } else {
+        r.cldl = r.ltmp1 = r.ltmp2 = r.cldi = r.itmp11 = r.itmp12 = r.itmp2 = T(0.0);
+        r.prr = T(0.0);
+        r.prs = T(0.0);
+    }
+    // :340-353
+    const T dr1 = cons2 * r.dp * (r.prr + r.prs);
+    if (t < e.RTT) {
+        r.rfreeze1 = cons2 * r.dp * r.prr;
+        r.fwatr1 = T(0.0);
+    } else {
+        r.rfreeze1 = T(0.0);
+        r.fwatr1 = T(1.0);
+    }
+    rfln += r.fwatr1 * dr1;
+    sfln += (T(1.0) - r.fwatr1) * dr1;
+    // :401-419 (evapr = evaps = 0)
+    const T hh = x.lude * (r.fwat * r.lvdcp + (T(1.0) - r.fwat) * r.lsdcp);
+    const T dqdt = -(r.condl1 + r.condi1) + x.lude * r.gdp;
+    const T dtdt = r.lvdcp * r.condl1 + r.lsdcp * r.condi1 - (hh - (r.lsdcp - r.lvdcp) * r.rfreeze1) * r.gdp;
+    r.t3 = t + dt * dtdt;
+    q = r.q2 + dt * dqdt;
+    r.qold = q;
+    // :422
+    t = r.t3;
+    cuadj_fwd_save(e, x.ap, t, q, r.adj);
+    r.t_post = t;
+    r.q_post = q;
+    r.t3_cold = r.t3 < e.RTT;
+    r.tpost_cold = t < e.RTT;
+    // :425-439
+    r.dq = rmax<T>(r.qold - q, T(0.0));
+    r.dr2 = cons2 * r.dp * r.dq;
+    const bool frz2 = FIX ? r.tpost_cold : r.t3_cold;  // Q4
+    T rfreeze2;
+    if (frz2) {
+        rfreeze2 = r.fwat * r.dr2;
+        r.fwatr2 = T(0.0);
+    } else {
+        rfreeze2 = T(0.0);
+        r.fwatr2 = T(1.0);
+    }
+    r.condl2 = r.condl1 + r.fwatr2 * r.dq / dt;
+    r.condi2 = r.condi1 + (T(1.0) - r.fwatr2) * r.dq / dt;
+    rfln += r.fwatr2 * r.dr2;
+    sfln += (T(1.0) - r.fwatr2) * r.dr2;
+    r.rfreeze3 = r.rfreeze1 + rfreeze2;
+    // :442-455
+    r.tnd_q = -(r.condl2 + r.condi2) + x.lude * r.gdp;
+    r.tnd_t = r.lvdcp * r.condl2 + r.lsdcp * r.condi2 - (hh - (r.lsdcp - r.lvdcp) * r.rfreeze3) * r.gdp;
+    r.tnd_ql = (qlwc - r.ql) / dt;
+    r.tnd_qi = (qiwc - r.qi) / dt;
+    r.rfln = rfln;
+    r.sfln = sfln;
+}
+
+// Adjoint forcing of one level: the perturbations of the 10 NL outputs that level k feeds.
+template <typename T>
+struct ADForce {
+    T clc, tnd_q, tnd_qi, tnd_ql, tnd_t, fplsl1, fplsn1;  // flux forcings at half level k+1, already
+                                                          // combined with the enthalpy-flux ones (:481-484)
+};
+
+template <typename T>
+__device__ __forceinline__ ADForce<T> ad_load_force(const CPtrs<T, NL_NUM_OUT>& a, const Ext<T>& e, int64_t ls,
+                                                    int col, int k) {
+    const int64_t o = int64_t(k) * ls + col;
+    ADForce<T> f;
+    f.clc = a.p[NL_OUT_CLC][o];
+    f.tnd_q = a.p[NL_OUT_TND_Q][o];
+    f.tnd_qi = a.p[NL_OUT_TND_QI][o];
+    f.tnd_ql = a.p[NL_OUT_TND_QL][o];
+    f.tnd_t = a.p[NL_OUT_TND_T][o];
+    f.fplsl1 = a.p[NL_OUT_FPLSL][o + ls] - a.p[NL_OUT_FHPSL][o + ls] * e.RLVTT;
+    f.fplsn1 = a.p[NL_OUT_FPLSN][o + ls] - a.p[NL_OUT_FHPSN][o + ls] * e.RLSTT;
+    return f;
+}
+
+template <typename T>
+struct ADBack {   // carried from level k+1 to level k in the backward sweep
+    T tmp_rfln_i, tmp_sfln_i, rfl_i, sfl_i, daph_i, dp_i;
+};
+
+template <typename T>
+struct ADOut {
+    T ap, t, q, ql, qi, qsat, lude, mfd, mfu, aph1, lu1;
+};
+
+// Backward statements of one level (:494-967 + this level's share of :970-996).
+template <typename T, bool REG, bool FIX>
+__device__ __forceinline__ ADOut<T> ad_backward(const Ext<T>& e, const ADIn<T>& x, T aph_k, int k, T scalm, T dt,
+                                                T sfl, const ADTraj<T>& r, const ADForce<T>& f, ADBack<T>& b) {
+    ADOut<T> o;
+    const T ckcodtl = T(2.0) * e.RKCONV * dt;
+    const T ckcodti = T(5.0) * e.RKCONV * dt;
+    const T ckcodtla = ckcodtl / T(100.0);
+    const T ckcodtia = ckcodti / T(100.0);
+    const T cons2 = T(1.0) / (e.RG * dt);
+    const T meltp2 = e.RTT + T(2.0);
+    const T lvdcp = r.lvdcp, lsdcp = r.lsdcp, fwat = r.fwat, gdp = r.gdp;
+    // :500-501
+    T tmp_rfln_i = b.tmp_rfln_i + b.rfl_i + f.fplsl1;
+    T tmp_sfln_i = b.tmp_sfln_i + b.sfl_i + f.fplsn1;
+    // :504-511
+    T o_qi = -f.tnd_qi / dt;
+    T qiwc_i = f.tnd_qi / dt;
+    T o_ql = -f.tnd_ql / dt;
+    T qlwc_i = f.tnd_ql / dt;
+    // :514-533 (evapr = evaps = 0)
+    const T tt = f.tnd_t;
+    const T mix = fwat * lvdcp + (T(1.0) - fwat) * lsdcp;
+    const T hh = x.lude * mix;
+    T gdp_i = -tt * (hh - (lsdcp - lvdcp) * r.rfreeze3);
+    T condl_i = tt * lvdcp;
+    T condi_i = tt * lsdcp;
+    T lvdcp_i = tt * r.condl2;
+    T lsdcp_i = tt * r.condi2;
+    T o_lude = -tt * gdp * mix;
+    lvdcp_i -= tt * x.lude * gdp * fwat;
+    lsdcp_i -= tt * x.lude * gdp * (T(1.0) - fwat);
+    T fwat_i = -tt * x.lude * gdp * (lvdcp - lsdcp);
+    lvdcp_i -= tt * r.rfreeze3 * gdp;
+    lsdcp_i += tt * r.rfreeze3 * gdp;
+    T rfreeze_i = tt * (lsdcp - lvdcp) * gdp;
+    // :536-542
+    const T tq = f.tnd_q;
+    gdp_i += tq * x.lude;
+    o_lude += tq * gdp;
+    condl_i -= tq;
+    condi_i -= tq;
+    // :566-592
+    T dq_i = (r.fwatr2 * condl_i + (T(1.0) - r.fwatr2) * condi_i) / dt;
+    T dr2_i = r.fwatr2 * tmp_rfln_i + (T(1.0) - r.fwatr2) * tmp_sfln_i;
+    if (FIX ? r.tpost_cold : r.t3_cold) {  // :577
+        fwat_i += r.dr2 * rfreeze_i;
+        dr2_i += fwat * rfreeze_i;
+    }
+    dq_i += cons2 * r.dp * dr2_i;
+    T dp_i = cons2 * r.dq * dr2_i;
+    T qold_i, o_q;
+    if (r.qold >= r.q_post) {
+        if constexpr (REG) dq_i *= T(0.7);
+        qold_i = dq_i;
+        o_q = -dq_i;
+    } else {
+        qold_i = T(0.0);
+        o_q = T(0.0);
+    }
+    // :594-598
+    T o_ap = T(0.0), o_t = T(0.0);
+    cuadj_bwd(e, r.adj, x.ap, o_ap, o_t, o_q);
+    // :601-633
+    o_q += qold_i;
+    const T dqdt_i = dt * o_q;
+    const T dtdt_i = dt * o_t;
+    gdp_i -= dtdt_i * (hh - (lsdcp - lvdcp) * r.rfreeze1);
+    condl_i += dtdt_i * lvdcp;
+    condi_i += dtdt_i * lsdcp;
+    lvdcp_i += dtdt_i * r.condl1;
+    lsdcp_i += dtdt_i * r.condi1;
+    o_lude -= dtdt_i * gdp * mix;
+    lvdcp_i -= dtdt_i * x.lude * gdp * fwat;
+    lsdcp_i -= dtdt_i * x.lude * gdp * (T(1.0) - fwat);
+    fwat_i -= dtdt_i * x.lude * gdp * (lvdcp - lsdcp);
+    lvdcp_i -= dtdt_i * r.rfreeze1 * gdp;
+    lsdcp_i += dtdt_i * r.rfreeze1 * gdp;
+    rfreeze_i += dtdt_i * (lsdcp - lvdcp) * gdp;
+    gdp_i += dqdt_i * x.lude;
+    o_lude += dqdt_i * gdp;
+    condl_i -= dqdt_i;
+    condi_i -= dqdt_i;
+    // :710-719 (no evaporation): corqs_i = covpclr_i = covptot_i = daph_i = out_qsat_i = prtot_i = qlim_i = 0
+    T daph_i = T(0.0);
+    T o_qsat = T(0.0);
+    // :722-736
+    const T dr_i = r.fwatr1 * tmp_rfln_i + (T(1.0) - r.fwatr1) * tmp_sfln_i;
+    T prr_i;
+    if (FIX ? (r.fwatr1 == T(0.0)) : r.tpost_cold) {  // :729 (Q5)
+        dp_i += rfreeze_i * cons2 * r.prr;
+        prr_i = rfreeze_i * cons2 * r.dp;
+    } else {
+        prr_i = T(0.0);
+    }
+    prr_i += cons2 * r.dp * dr_i;
+    T prs_i = cons2 * r.dp * dr_i;
+    dp_i += cons2 * (r.prr + r.prs) * dr_i;
+    // :738-782
+    T a_clc = f.clc;
+    if (r.cloudy) {
+        const T icrit = T(2.0) * e.RCLCRIT;
+        prs_i -= qiwc_i;
+        qiwc_i += prs_i;
+        const T qinew_i = -prs_i;
+        a_clc += qinew_i * r.cldi * r.itmp2;
+        T cldi_i = qinew_i * r.out_clc * r.itmp2;
+        const T di_i = -qinew_i * r.out_clc * r.cldi * r.itmp2;
+        const T itmp4 = REG ? ckcodtia : ckcodti;
+        o_t += T(0.025) * itmp4 * r.itmp12 * (T(1.0) - r.itmp11) * di_i;
+        cldi_i += T(2.0) * itmp4 * r.itmp12 * r.itmp11 * r.cldi * di_i / sq(icrit);
+        qiwc_i += cldi_i / r.out_clc;
+        a_clc -= r.qiwc1 * cldi_i / sq(r.out_clc);
+        const T lcrit = T(2.0) * e.RCLCRIT;
+        prr_i -= qlwc_i;
+        qlwc_i += prr_i;
+        const T qlnew_i = -prr_i;
+        a_clc += qlnew_i * r.cldl * r.ltmp2;
+        T cldl_i = qlnew_i * r.out_clc * r.ltmp2;
+        const T dl_i = -qlnew_i * r.out_clc * r.cldl * r.ltmp2;
+        const T ltmp4 = REG ? ckcodtla : ckcodtl;
+        cldl_i += T(2.0) * ltmp4 * r.ltmp1 * r.cldl * dl_i / sq(lcrit);
+        qlwc_i += cldl_i / r.out_clc;
+        a_clc -= r.qlwc1 * cldl_i / sq(r.out_clc);
+    }
+    // :785-806 melting of incoming snow
+    T lfdcp_i;
+    if (r.melt) {
+        const T snmlt_i = -o_t / r.cons + tmp_rfln_i - tmp_sfln_i;
+        T cons_i = o_t * r.snmlt / sq(r.cons);
+        b.rfl_i = tmp_rfln_i;
+        tmp_rfln_i = T(0.0);
+        b.sfl_i = tmp_sfln_i;
+        tmp_sfln_i = T(0.0);
+        T z2s_i;
+        if (sfl <= r.z2s) {
+            b.sfl_i += snmlt_i;
+            z2s_i = T(0.0);
+        } else {
+            z2s_i = snmlt_i;
+        }
+        if (r.t2 > meltp2) {
+            o_t += r.cons * z2s_i;
+            cons_i += (r.t2 - meltp2) * z2s_i;
+        }
+        dp_i += cons2 * cons_i / r.lfdcp;
+        lfdcp_i = -cons2 * r.dp * cons_i / sq(r.lfdcp);
+    } else {
+        lfdcp_i = T(0.0);
+        b.rfl_i = T(0.0);  // Q8
+        b.sfl_i = T(0.0);
+    }
+    b.tmp_rfln_i = tmp_rfln_i;
+    b.tmp_sfln_i = tmp_sfln_i;
+    // :810-817: covpclr_i = covptot_i = 0 without the evaporation block -> no contribution
+    // :820-825
+    qiwc_i += condi_i / dt;
+    o_qi -= condi_i / dt;
+    qlwc_i += condl_i / dt;
+    o_ql -= condl_i / dt;
+    T qc_i = fwat * qlwc_i + (T(1.0) - fwat) * qiwc_i;
+    fwat_i += r.qc3 * (qlwc_i - qiwc_i);
+    // :828-842
+    T dqc_i = -qc_i;
+    T dqsdz_i, rho_i;
+    if (r.lo3) {
+        if constexpr (REG) dqc_i *= T(0.1);
+        dqsdz_i = dt * dqc_i * (x.mfd + x.mfu) * r.fac4;
+        o.mfd = dt * dqc_i * r.dqsdz * r.fac4;
+        o.mfu = o.mfd;
+        rho_i = -dqc_i * r.dqc * r.fac4;
+    } else {
+        qc_i += dqc_i;
+        dqsdz_i = T(0.0);
+        o.mfd = T(0.0);
+        o.mfu = T(0.0);
+        rho_i = T(0.0);
+    }
+    // :844-855
+    const T dtdzmo_i = dqsdz_i * r.dqsdtemp;
+    T dqsdtemp_i = dqsdz_i * r.dtdzmo - r.dtdzmo * dtdzmo_i * r.ldcp * r.fac3;
+    const T rodqsdp_i = -e.RG * (dqsdz_i + dtdzmo_i * r.ldcp * r.fac3);
+    const T ldcp_i = -dtdzmo_i * (e.RG * r.rodqsdp + r.dtdzmo * r.dqsdtemp) * r.fac3;
+    fwat_i += ldcp_i * (lvdcp - lsdcp);
+    lvdcp_i += fwat * ldcp_i;
+    lsdcp_i += (T(1.0) - fwat) * ldcp_i;
+    rho_i -= rodqsdp_i * x.qsat * r.fac2;
+    o_qsat -= rodqsdp_i * r.rho * r.fac2;
+    o_ap += rodqsdp_i * r.rho * x.qsat * sq(r.fac2) + rho_i * r.fac1;
+    T foeew_i = -e.RETV * rodqsdp_i * r.rho * x.qsat * sq(r.fac2);
+    o_t -= rho_i * x.ap * r.fac1 / r.t2;
+    // :858-877 convective detrainment
+    T lude_i, dlu_i;
+    if (k < e.NLEV - 1 && r.lude >= e.RLMIN && x.lu1 >= e.ZEPS2) {
+        const T ex = rexp<T>(-r.lude / x.lu1);
+        lude_i = qc_i + (T(1.0) - r.clc) / x.lu1 * ex * a_clc;
+        dlu_i = (T(1.0) - r.clc) * r.lude / sq(x.lu1) * ex * a_clc;
+        a_clc *= T(1.0) - (T(1.0) - ex);
+    } else {
+        lude_i = T(0.0);
+        dlu_i = T(0.0);
+    }
+    o_lude += dt * gdp * lude_i;
+    gdp_i += dt * x.lude * lude_i;
+    daph_i += e.RG * gdp_i / sq(x.aph1 - aph_k);
+    // :880-918 Le Treut & Li cloud fraction
+    T qt_i = T(0.0), qsat_i, qcrit_i;
+    if (r.qt < r.qcrit) {
+        qsat_i = T(0.0);
+        qcrit_i = T(0.0);
+    } else if (r.qt >= r.qsat) {
+        qsat_i = (T(1.0) - scalm) * qc_i;
+        qcrit_i = -(T(1.0) - scalm) * qc_i;
+    } else {
+        T qpd_i = scalm * qc_i * sq(r.clc);
+        T qcd_i = (T(1.0) - scalm) * qc_i * sq(r.clc);
+        a_clc += T(2.0) * (scalm * r.qpd + (T(1.0) - scalm) * r.qcd) * r.clc * qc_i;
+        if constexpr (REG) {
+            const T rat = r.qpd / r.qcd;
+            const T yyy = rmin<T>(T(0.3), T(3.5) * rsqrt_<T>(rat * cube(T(1.0) - scalm * (T(1.0) - rat))) /
+                                              (T(1.0) - scalm));
+            a_clc *= yyy;
+        }
+        const T den = r.qcd - scalm * (r.qt - r.qcrit);
+        qpd_i -= T(0.5) / r.tmp3 * a_clc / den;
+        qcd_i += T(0.5) / r.tmp3 * r.qpd * a_clc / sq(den);
+        qt_i = (T(-0.5) / r.tmp3 * (r.qpd * scalm * a_clc) / sq(den)) - qpd_i;
+        qcrit_i = (T(0.5) / r.tmp3 * (r.qpd * scalm * a_clc) / sq(den)) - qcd_i;
+        qsat_i = qcd_i + qpd_i;
+    }
+    // :920-938
+    o_q += qt_i;
+    o_ql += qt_i;
+    o_qi += qt_i;
+    qsat_i += qcrit_i * r.crh2;
+    o_qsat += qsat_i * r.supsat;
+    const T supsat_i = qsat_i * x.qsat;
+    if (r.t2 < e.RTICE) o_t -= T(0.003) * supsat_i;
+    // :941-967 (corqs_i = qlim_i = 0)
+    o_qsat += r.fac * r.cor * dqsdtemp_i;
+    const T cor_i = r.fac * x.qsat * dqsdtemp_i;
+    const T fac_i = r.cor * x.qsat * dqsdtemp_i;
+    T esdp_i = e.RETV * cor_i * sq(r.cor);
+    const T facw_i = fwat * fac_i;
+    const T faci_i = (T(1.0) - fwat) * fac_i;
+    fwat_i += (r.facw - r.faci) * fac_i;
+    o_t -= T(2.0) * (e.R5IES * faci_i / cube(r.t2 - e.R4IES) + e.R5LES * facw_i / cube(r.t2 - e.R4LES));
+    if (r.esdp1 > e.ZQMAX) esdp_i = T(0.0);
+    foeew_i += esdp_i / x.ap;
+    o_ap -= esdp_i * r.foeew / sq(x.ap);
+    T z3es, z4es;
+    if (r.t2 < e.RTT) {
+        z3es = e.R3IES;
+        z4es = e.R4IES;
+    } else {
+        z3es = e.R3LES;
+        z4es = e.R4LES;
+    }
+    o_t += z3es * (e.RTT - z4es) * foeew_i * r.foeew / sq(r.t2 - z4es);
+    if (r.t2 < e.RTT) o_t += T(0.545) * T(0.17) * fwat_i / sq(rcosh<T>(T(0.17) * (r.t2 - e.RLPTRC)));
+    // :988-991
+    const T zzv = e.RLVTT * lvdcp_i + e.RLSTT * lsdcp_i + e.RLMLT * lfdcp_i;
+    o_q += -zzv * e.RCPD * e.RVTMP2 / sq(e.RCPD + e.RCPD * e.RVTMP2 * r.q_post);
+    // :970-986 staggered corrections for half level k+1 (uses level k+1's daph_i / dp_i)
+    o.aph1 = b.daph_i - daph_i - b.dp_i + dp_i;
+    o.lu1 = -dlu_i;
+    b.daph_i = daph_i;
+    b.dp_i = dp_i;
+    o.ap = o_ap;
+    o.t = o_t;
+    o.q = o_q;
+    o.ql = o_ql;
+    o.qi = o_qi;
+    o.qsat = o_qsat;
+    o.lude = o_lude;
+    return o;
+}
+
+template <typename T>
+__device__ __forceinline__ T ad_trpaus(const T* __restrict__ pt, const T* __restrict__ ptt, int64_t ls, int col,
+                                       T dt, const T* s_eta, int klo, int khi) {
+    T trpaus = T(0.1);
+    if (klo <= khi) {
+        T tk = pt[int64_t(klo) * ls + col] + dt * ptt[int64_t(klo) * ls + col];
+        for (int k = klo; k <= khi; ++k) {
+            const int64_t o1 = int64_t(k + 1) * ls + col;
+            const T tk1 = pt[o1] + dt * ptt[o1];
+            const T ek = s_eta[k];
+            if (ek > T(0.1) && ek < T(0.4) && tk > tk1) trpaus = ek;
+            tk = tk1;
+        }
+    }
+    return trpaus;
+}
+
+template <typename T, bool REG, bool FIX>
+__global__ void __launch_bounds__(kWave)
+ad_kernel(Ext<T> e, int nx, int nz, int64_t ls, CPtrs<T, NL_NUM_IN> in, CPtrs<T, NL_NUM_OUT> adj,
+          const T* __restrict__ eta, MPtrs<T, NL_NUM_OUT> out, MPtrs<T, NL_NUM_IN> oadj, T dt) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    T* s_eta = reinterpret_cast<T*>(smem_raw);
+    T* s_scalm = s_eta + (nz + 1);
+    int klo, khi;
+    build_level_table<T>(eta, nz, e, s_eta, s_scalm, klo, khi);
+
+    const int gcol = blockIdx.x * kWave + threadIdx.x;
+    if (gcol >= nx) return;  // no later workgroup barrier: whole lanes may retire
+    const int col = gcol;
+
+    const T trpaus = ad_trpaus<T>(in.p[NL_IN_T], in.p[NL_IN_TND_CML_T], ls, col, dt, s_eta, klo, khi);
+    const CrhCol<T> crh = crh_setup<T>(trpaus);
+
+    // ---------------- sweep 1: trajectory + NL outputs (:146-475)
+    out.p[NL_OUT_FPLSL][col] = T(0.0);
+    out.p[NL_OUT_FPLSN][col] = T(0.0);
+    out.p[NL_OUT_FHPSL][col] = T(0.0);
+    out.p[NL_OUT_FHPSN][col] = T(0.0);
+    {
+        T rfl = T(0.0), sfl = T(0.0);
+        T aph_k = in.p[NL_IN_APH][col];
+        ADIn<T> xa = ad_load<T>(in, ls, col, 0);
+        for (int k = 0; k < nz; ++k) {
+            ADIn<T> xn = xa;
+            if (k + 1 < nz) xn = ad_load<T>(in, ls, col, k + 1);
+            ADTraj<T> r;
+            ad_forward<T, FIX>(e, xa, aph_k, k, s_eta[k], s_scalm[k], crh, dt, rfl, sfl, r);
+            const int64_t i = int64_t(k) * ls + col;
+            out.p[NL_OUT_CLC][i] = r.out_clc;
+            out.p[NL_OUT_COVPTOT][i] = T(0.0);
+            out.p[NL_OUT_TND_Q][i] = r.tnd_q;
+            out.p[NL_OUT_TND_T][i] = r.tnd_t;
+            out.p[NL_OUT_TND_QL][i] = r.tnd_ql;
+            out.p[NL_OUT_TND_QI][i] = r.tnd_qi;
+            out.p[NL_OUT_FPLSL][i + ls] = r.rfln;
+            out.p[NL_OUT_FPLSN][i + ls] = r.sfln;
+            out.p[NL_OUT_FHPSL][i + ls] = -r.rfln * e.RLVTT;
+            out.p[NL_OUT_FHPSN][i + ls] = -r.sfln * e.RLSTT;
+            rfl = r.rfln;
+            sfl = r.sfln;
+            aph_k = xa.aph1;
+            xa = xn;
+        }
+    }
+
+    // ---------------- sweep 2: adjoint (:479-996), k = nz-1 .. 0
+    ADBack<T> b;
+    b.tmp_rfln_i = b.tmp_sfln_i = b.rfl_i = b.sfl_i = b.daph_i = b.dp_i = T(0.0);
+    {
+        int k = nz - 1;
+        ADIn<T> xa = ad_load<T>(in, ls, col, k);
+        ADForce<T> fa = ad_load_force<T>(adj, e, ls, col, k);
+        T aph_k = in.p[NL_IN_APH][int64_t(k) * ls + col];
+        T sfl = out.p[NL_OUT_FPLSN][int64_t(k) * ls + col];
+        T rfl = out.p[NL_OUT_FPLSL][int64_t(k) * ls + col];
+        for (; k >= 0; --k) {
+            ADIn<T> xn = xa;
+            ADForce<T> fn = fa;
+            T aph_n = aph_k, sfl_n = sfl, rfl_n = rfl;
+            if (k > 0) {
+                xn = ad_load<T>(in, ls, col, k - 1);
+                fn = ad_load_force<T>(adj, e, ls, col, k - 1);
+                aph_n = in.p[NL_IN_APH][int64_t(k - 1) * ls + col];
+                sfl_n = out.p[NL_OUT_FPLSN][int64_t(k - 1) * ls + col];
+                rfl_n = out.p[NL_OUT_FPLSL][int64_t(k - 1) * ls + col];
+            }
+            ADTraj<T> r;
+            ad_forward<T, FIX>(e, xa, aph_k, k, s_eta[k], s_scalm[k], crh, dt, rfl, sfl, r);
+            const ADOut<T> o = ad_backward<T, REG, FIX>(e, xa, aph_k, k, s_scalm[k], dt, sfl, r, fa, b);
+            const int64_t i = int64_t(k) * ls + col;
+            oadj.p[NL_IN_AP][i] = o.ap;
+            oadj.p[NL_IN_T][i] = o.t;
+            oadj.p[NL_IN_Q][i] = o.q;
+            oadj.p[NL_IN_QL][i] = o.ql;
+            oadj.p[NL_IN_QI][i] = o.qi;
+            oadj.p[NL_IN_QSAT][i] = o.qsat;
+            oadj.p[NL_IN_LUDE][i] = o.lude;
+            oadj.p[NL_IN_MFD][i] = o.mfd;
+            oadj.p[NL_IN_MFU][i] = o.mfu;
+            oadj.p[NL_IN_SUPSAT][i] = dt * o.q;           // :992 (Q7, literal)
+            oadj.p[NL_IN_TND_CML_T][i] = dt * o.t;        // :993-996
+            oadj.p[NL_IN_TND_CML_Q][i] = dt * o.q;
+            oadj.p[NL_IN_TND_CML_QL][i] = dt * o.ql;
+            oadj.p[NL_IN_TND_CML_QI][i] = dt * o.qi;
+            oadj.p[NL_IN_APH][i + ls] = o.aph1;
+            oadj.p[NL_IN_LU][i + ls] = o.lu1;
+            xa = xn;
+            fa = fn;
+            aph_k = aph_n;
+            sfl = sfl_n;
+            rfl = rfl_n;
+        }
+    }
+    // :982-986 top half level
+    oadj.p[NL_IN_APH][col] = b.daph_i - b.dp_i;
+    oadj.p[NL_IN_LU][col] = T(0.0);
+}
+
+template <typename T>
+int launch_ad(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* const* in, const T* const* in_adj,
+              const T* eta, T* const* out, T* const* out_adj, double dt, hipStream_t stream) {
+    if (p.LEVAPLS2 || p.LDRAIN1D) return -2;
+    const Ext<T> e = make_ext<T>(p);
+    CPtrs<T, NL_NUM_IN> ci;
+    CPtrs<T, NL_NUM_OUT> ca;
+    MPtrs<T, NL_NUM_OUT> co;
+    MPtrs<T, NL_NUM_IN> coa;
+    for (int i = 0; i < NL_NUM_IN; ++i) { ci.p[i] = in[i]; coa.p[i] = out_adj[i]; }
+    for (int i = 0; i < NL_NUM_OUT; ++i) { ca.p[i] = in_adj[i]; co.p[i] = out[i]; }
+    const dim3 grid((nx + kWave - 1) / kWave), block(kWave);
+    const size_t smem = 2 * size_t(nz + 1) * sizeof(T);
+    const T tdt = static_cast<T>(dt);
+    const bool reg = p.LREGCL != 0;
+    const bool fix = p.AD_TRAJ_FIX != 0;
+#define CS2_AD_LAUNCH(R, F) \
+    hipLaunchKernelGGL((ad_kernel<T, R, F>), grid, block, smem, stream, e, nx, nz, ls, ci, ca, eta, co, coa, tdt)
+    if (reg && !fix) CS2_AD_LAUNCH(true, false);
+    else if (!reg && !fix) CS2_AD_LAUNCH(false, false);
+    else if (reg && fix) CS2_AD_LAUNCH(true, true);
+    else CS2_AD_LAUNCH(false, true);
+#undef CS2_AD_LAUNCH
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+template int launch_ad<double>(const Cloudsc2Params&, int, int, int64_t, const double* const*, const double* const*,
+                               const double*, double* const*, double* const*, double, hipStream_t);
+template int launch_ad<float>(const Cloudsc2Params&, int, int, int64_t, const float* const*, const float* const*,
+                              const float*, float* const*, float* const*, double, hipStream_t);
+
+}  // namespace cs2

@@ -31,6 +31,7 @@ _REAL_FIELDS = (
 )
 _INT_FIELDS = (
     "LPHYLIN", "LDRAIN1D", "LEVAPLS2", "LREGCL", "ICALL", "KFLAG", "IGNORE_SUPSAT", "NLEV",
+    "AD_TRAJ_FIX",  # build extension (not a reference external), see include/cloudsc2_hip.h
 )
 
 ABI_VERSION = 1
@@ -79,6 +80,7 @@ def default_externals() -> Dict[str, Any]:
         # literals set by the components
         ICALL=0, LDRAIN1D=False, ZEPS1=1.0e-12, ZEPS2=1.0e-10, ZQMAX=0.5, ZSCAL=0.9,
         QMAX=0.5, KFLAG=1, IGNORE_SUPSAT=False, NLEV=137,
+        AD_TRAJ_FIX=0,
     )
     return ext
 

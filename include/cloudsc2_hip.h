@@ -52,6 +52,12 @@ typedef struct Cloudsc2Params {
     double RCLCRIT, RKCONV, RLMIN, RPECONS, RLPTRC;
     double ZEPS1, ZEPS2, ZQMAX, ZSCAL, QMAX;
     int32_t LPHYLIN, LDRAIN1D, LEVAPLS2, LREGCL, ICALL, KFLAG, IGNORE_SUPSAT, NLEV;
+    /* Build extension, NOT a reference external (default 0 = reproduce the reference literally).
+     * 1: cloudsc2_ad uses the freezing tests of the NL/TL stencils (post-adjustment t < RTT at
+     * adjoint/_stencils/cloudsc2.py:427,:577; the forward test of :343 at :729), which makes AD the
+     * exact transpose of TL also in columns where the saturation adjustment crosses RTT
+     * (SURVEY.md Appendix B Q4/Q5). */
+    int32_t AD_TRAJ_FIX;
 } Cloudsc2Params;
 
 int32_t cloudsc2_abi_version(void);

@@ -91,3 +91,97 @@ def assert_close(name: str, got: np.ndarray, want: np.ndarray, dtype=None, scale
             f"got {got[i]!r}, want {want[i]!r}, |err| {err[i]:.3e}, bound {bound[i]:.3e}, scale {scale:.3e}"
         )
     return float(err.max() / scale) if scale > 0 else 0.0
+
+
+# ----------------------------------------------------------------------------------------------
+# TL / AD cases
+# ----------------------------------------------------------------------------------------------
+def increments(fields, f: float = 0.01, ignore_supsat: bool = False):
+    """`state_increment` (common/_stencils/state_increment.py:61-80): x_i = f * x for the 16 inputs."""
+    out = {k + "_i": (f * v).astype(v.dtype) for k, v in fields.items()}
+    if ignore_supsat:
+        out["in_supsat_i"] = np.zeros_like(fields["in_supsat"])
+    return out
+
+
+def run_oracle_tl(fields, fields_i, eta, dt, ext):
+    F = dict(fields)
+    F.update(fields_i)
+    for n in NL_OUT:
+        F["out_" + n] = np.zeros_like(fields["in_ap"])
+        F["out_" + n + "_i"] = np.zeros_like(fields["in_ap"])
+    oracle.cloudsc2_tl(F, eta, dt, ext)
+    return ({n: F["out_" + n] for n in NL_OUT}, {n: F["out_" + n + "_i"] for n in NL_OUT})
+
+
+def run_oracle_ad(fields, forcing, eta, dt, ext):
+    """forcing: dict NL_OUT name -> adjoint forcing array.  Returns (nl_outputs, adjoint_outputs)."""
+    F = dict(fields)
+    for n in NL_OUT:
+        F["in_" + n + "_i"] = forcing[n].copy()
+        F["out_" + n] = np.zeros_like(fields["in_ap"])
+    for n in NL_IN:
+        F["out_" + n + "_i"] = np.zeros_like(fields["in_ap"])
+    oracle.cloudsc2_ad(F, eta, dt, ext)
+    return ({n: F["out_" + n] for n in NL_OUT}, {n: F["out_" + n + "_i"] for n in NL_IN})
+
+
+def nlev_of(name: str, nz: int) -> int:
+    """number of levels a stencil writes for a field: half-level fields (aph, fluxes) nz+1, others nz"""
+    half = name in ("aph", "fhpsl", "fhpsn", "fplsl", "fplsn")
+    return nz + 1 if half else nz
+
+
+def taylor_norms(nl0, nlp_of_f2, tl_i, f2s):
+    """TaylorTest.get_norm (tangent_linear/validation.py:219-261) for each factor2."""
+    import sys as _sys
+
+    names = ("tnd_t", "tnd_q", "tnd_ql", "tnd_qi", "clc", "fhpsl", "fhpsn", "fplsl", "fplsn", "covptot")
+    norms = []
+    for f2 in f2s:
+        nlp = nlp_of_f2(f2)
+        tot, cnt = 0.0, 0
+        for n in names:
+            den = abs(f2 * tl_i[n].sum())
+            norm = abs((nlp[n] - nl0[n]).sum()) / den if den > _sys.float_info.epsilon else 0
+            cnt += norm > 0
+            tot += norm
+        norms.append(tot / cnt if cnt else 0.0)
+    return np.array(norms)
+
+
+def taylor_verdict(norms):
+    """TaylorTest.validate scoring (tangent_linear/validation.py:183-217) -> (passed, message)."""
+    e = np.abs(1 - np.asarray(norms, dtype=float))
+    start = -1
+    for i in range(e.size):
+        if start == -1 and e[i] < 0.5:
+            start = i
+    if start == -1 or start > 3:
+        return False, "The test failed with error 13."
+    test, negat = -10, 1
+    for i in range(start, e.size - 1):
+        tmp_negat = int(e[i + 1] < e[i])
+        if negat > tmp_negat:
+            test += 10
+        negat = tmp_negat
+    if test == -10:
+        test = 11
+    if np.min(e[start:]) > 1e-5:
+        test += 7
+    if np.min(e[start:]) > 1e-6:
+        test += 5
+    if test > 5:
+        return False, f"The test failed with error {test}."
+    return True, f"The test passed with penalty {test}. HOORAY!"
+
+
+def symmetry_norm3(tl_out_i, fields_i, ad_out_i, dtype=np.float64):
+    """SymmetryTest norms (adjoint/validation.py:157-215): per-column |norm1 - norm2| / (eps norm2)."""
+    norm1 = sum((tl_out_i[n].astype(np.float64) ** 2).sum(axis=0) for n in NL_OUT)
+    norm2 = sum((fields_i["in_" + n + "_i"].astype(np.float64) * ad_out_i[n].astype(np.float64)).sum(axis=0)
+                for n in NL_IN)
+    eps = np.finfo(dtype).eps
+    with np.errstate(divide="ignore", invalid="ignore"):
+        norm3 = np.where(norm2 == 0, abs(norm1 - norm2) / eps, abs(norm1 - norm2) / (eps * norm2))
+    return norm1, norm2, norm3

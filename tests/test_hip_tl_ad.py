@@ -1,0 +1,235 @@
+"""GPU parity of cloudsc2_tl / cloudsc2_ad / state_increment / perturbed_state against the oracle,
+plus the reference's own acceptance tests run on the HIP kernels: the TL Taylor test
+(tangent_linear/validation.py:150-217) and the AD symmetry test (adjoint/validation.py:132-165)."""
+import numpy as np
+import pytest
+
+from helpers import (NL_IN, NL_OUT, assert_close, externals, from_device, increments, nl_case, nlev_of,
+                     run_oracle_ad, run_oracle_nl, run_oracle_tl, symmetry_norm3, taylor_norms, taylor_verdict,
+                     to_device)
+
+pytestmark = pytest.mark.gpu
+INC = ("aph", "ap", "q", "qsat", "t", "ql", "qi", "lude", "lu", "mfu", "mfd",
+       "tnd_cml_t", "tnd_cml_q", "tnd_cml_ql", "tnd_cml_qi", "supsat")
+
+
+def _nan_outputs(names, nx, nz, dtype, device):
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd import storage
+
+    outs = {n: storage.zeros(nx, nz, dtype, device) for n in names}
+    for o in outs.values():
+        o.fill_(float("nan"))
+    return outs
+
+
+def run_hip_nl(dev_fields, eta_d, dt, ext, nx, nz, dtype, device):
+    import torch
+
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.stencils import compile_stencil
+
+    outs = _nan_outputs(["out_" + n for n in NL_OUT], nx, nz, dtype, device)
+    compile_stencil("cloudsc2_nl", ext)(**dev_fields, **outs, in_eta=eta_d, dt=dt, origin=(0, 0, 0),
+                                         domain=(nx, 1, nz + 1), validate_args=True, exec_info=None)
+    return outs
+
+
+def run_hip_tl(fields, fields_i, eta, dt, ext, device, nx, nz):
+    import torch
+
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.stencils import compile_stencil
+
+    dtype = fields["in_ap"].dtype
+    dev = to_device({**fields, **fields_i}, device)
+    outs = _nan_outputs(["out_" + n for n in NL_OUT] + ["out_" + n + "_i" for n in NL_OUT], nx, nz, dtype, device)
+    compile_stencil("cloudsc2_tl", ext)(
+        **dev, **outs, in_eta=torch.as_tensor(eta, device=device), tmp_klevel=None, tmp_aph_s=None,
+        dt=dtype.type(dt), origin=(0, 0, 0), domain=(nx, 1, nz + 1), validate_args=True, exec_info=None)
+    torch.cuda.synchronize()
+    return ({n: from_device(outs["out_" + n]) for n in NL_OUT},
+            {n: from_device(outs["out_" + n + "_i"]) for n in NL_OUT})
+
+
+def run_hip_ad(fields, forcing, eta, dt, ext, device, nx, nz):
+    import torch
+
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.stencils import compile_stencil
+
+    dtype = fields["in_ap"].dtype
+    dev = to_device(fields, device)
+    frc = to_device({"in_" + n + "_i": forcing[n] for n in NL_OUT}, device)
+    frc_before = {k: v.clone() for k, v in frc.items()}
+    outs = _nan_outputs(["out_" + n for n in NL_OUT] + ["out_" + n + "_i" for n in NL_IN], nx, nz, dtype, device)
+    compile_stencil("cloudsc2_ad", ext)(
+        **dev, **frc, **outs, in_eta=torch.as_tensor(eta, device=device), tmp_klevel=None,
+        dt=dtype.type(dt), origin=(0, 0, 0), domain=(nx, 1, nz + 1), validate_args=True, exec_info=None)
+    torch.cuda.synchronize()
+    for k in frc:  # documented choice (Q1): the forcings are left untouched
+        assert torch.equal(frc[k], frc_before[k]), k
+    return ({n: from_device(outs["out_" + n]) for n in NL_OUT},
+            {n: from_device(outs["out_" + n + "_i"]) for n in NL_IN})
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("regcl", [True, False])
+@pytest.mark.parametrize("nx", [64, 333])
+def test_tl_matches_oracle(gpu, nx, regcl, dtype):
+    ext = externals(LREGCL=regcl, NLEV=137)
+    fields, eta, dt = nl_case(nx, dtype=dtype)
+    fi = increments(fields, 0.01)
+    want, want_i = run_oracle_tl(fields, fi, eta, dt, ext)
+    got, got_i = run_hip_tl(fields, fi, eta, dt, ext, gpu, nx, 137)
+    for n in NL_OUT:
+        k = nlev_of(n, 137)
+        assert_close(f"tl out_{n}", got[n][:k], want[n][:k], dtype)
+        # perturbation outputs: compare on the scale of the field's perturbation
+        assert_close(f"tl out_{n}_i", got_i[n][:k], want_i[n][:k], dtype, rtol_mul=100.0)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("flags", [dict(), dict(LREGCL=False), dict(AD_TRAJ_FIX=1)])
+def test_ad_matches_oracle(gpu, flags, dtype):
+    nx = 200
+    ext = externals(NLEV=137, **flags)
+    fields, eta, dt = nl_case(nx, dtype=dtype)
+    fi = increments(fields, 0.01, ignore_supsat=True)
+    _, forcing = run_oracle_tl(fields, fi, eta, dt, ext)
+    want, want_i = run_oracle_ad(fields, forcing, eta, dt, ext)
+    got, got_i = run_hip_ad(fields, forcing, eta, dt, ext, gpu, nx, 137)
+    for n in NL_OUT:
+        k = nlev_of(n, 137)
+        assert_close(f"ad out_{n}", got[n][:k], want[n][:k], dtype)
+    for n in NL_IN:
+        # out_aph_i and out_lu_i are written on all nz+1 levels (adjoint/_stencils/cloudsc2.py:970-986)
+        k = 138 if n in ("aph", "lu") else 137
+        assert_close(f"ad out_{n}_i{flags}", got_i[n][:k], want_i[n][:k], dtype, rtol_mul=1000.0)
+        if k == 137:
+            assert np.isnan(got_i[n][137]).all(), n
+
+
+def test_taylor_test_on_the_gpu(gpu):
+    """BASELINE config 3 protocol at a size the oracle can follow (512 columns): saturation -> NL ->
+    state_increment(0.01) -> TL -> 10 x (perturbed_state(f2) -> NL), all through the HIP stencils;
+    norms as TaylorTest.get_norm.  LREGCL = False as TaylorTest forces (validation.py:84-85)."""
+    import torch
+
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd import storage
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.stencils import compile_stencil
+
+    nx, nz = 512, 137
+    ext = externals(LREGCL=False, NLEV=nz)
+    fields, eta, dt = nl_case(nx)
+    dev = to_device(fields, gpu)
+    eta_d = torch.as_tensor(eta, device=gpu)
+    # increments on the device
+    st = {"in_" + n: dev["in_" + n] for n in INC}
+    inc = {"out_" + n + "_i": storage.zeros(nx, nz, np.float64, gpu) for n in INC}
+    compile_stencil("state_increment", {"IGNORE_SUPSAT": False})(
+        **st, **inc, f=0.01, origin=(0, 0, 0), domain=(nx, 1, nz + 1), validate_args=True, exec_info=None)
+    dev_i = {"in_" + n + "_i": inc["out_" + n + "_i"] for n in INC}
+    nl0 = run_hip_nl(dev, eta_d, dt, ext, nx, nz, np.float64, gpu)
+    tl = _nan_outputs(["out_" + n for n in NL_OUT] + ["out_" + n + "_i" for n in NL_OUT], nx, nz, np.float64, gpu)
+    compile_stencil("cloudsc2_tl", ext)(**dev, **dev_i, **tl, in_eta=eta_d, dt=dt, origin=(0, 0, 0),
+                                         domain=(nx, 1, nz + 1), validate_args=True, exec_info=None)
+    pert = compile_stencil("perturbed_state", {})
+    sp = {"out_" + n: storage.zeros(nx, nz, np.float64, gpu) for n in INC}
+
+    def host(d, suffix=""):
+        return {n: from_device(d["out_" + n + suffix]) for n in NL_OUT}
+
+    nl0_h, tl_i_h = host(nl0), host(tl, "_i")
+    for n in NL_OUT:  # padding levels hold NaN by construction of the test: mask them
+        k = nlev_of(n, nz)
+        nl0_h[n], tl_i_h[n] = nl0_h[n][:k], tl_i_h[n][:k]
+
+    def nlp(f2):
+        pert(**st, **dev_i, **sp, f=f2, origin=(0, 0, 0), domain=(nx, 1, nz + 1), validate_args=True,
+             exec_info=None)
+        p = run_hip_nl({"in_" + n: sp["out_" + n] for n in INC}, eta_d, dt, ext, nx, nz, np.float64, gpu)
+        h = host(p)
+        return {n: h[n][:nlev_of(n, nz)] for n in NL_OUT}
+
+    f2s = tuple(10.0 ** -i for i in range(1, 11))
+    norms = taylor_norms(nl0_h, nlp, tl_i_h, f2s)
+    err = np.abs(1 - norms)
+    assert err.min() < 1e-6, norms
+    assert err[4:9].max() < 1e-4, norms
+    # the same experiment with the oracle gives the same norms (the kernels ARE the reference's math)
+    fi = increments(fields, 0.01)
+    o_nl0 = run_oracle_nl(fields, eta, dt, ext)
+    _, o_tl_i = run_oracle_tl(fields, fi, eta, dt, ext)
+    o_norms = taylor_norms(o_nl0, lambda f2: run_oracle_nl({k: fields[k] + f2 * fi[k + "_i"] for k in fields},
+                                                           eta, dt, ext), o_tl_i, f2s)
+    np.testing.assert_allclose(norms[:7], o_norms[:7], rtol=1e-6)
+    print("Taylor norms (HIP):", norms, taylor_verdict(norms))
+
+
+def test_symmetry_test_on_the_gpu(gpu):
+    """BASELINE config 4 protocol (512 columns): state_increment(0.01, ignore_supsat) -> TL -> AD on the
+    TL outputs; norm3 = |norm1 - norm2| / (eps norm2) per column, pass iff max < 1e4
+    (adjoint/validation.py:157-165).  With the reference's literal freezing tests the columns whose
+    adjustment crosses RTT fail, exactly as in the oracle; with AD_TRAJ_FIX every column passes."""
+    nx = 512
+    fields, eta, dt = nl_case(nx)
+    fi = increments(fields, 0.01, ignore_supsat=True)
+    ext = externals(NLEV=137)
+    _, tl_i = run_hip_tl(fields, fi, eta, dt, ext, gpu, nx, 137)
+    for n in NL_OUT:
+        tl_i[n][nlev_of(n, 137):] = 0.0
+    _, ad_i = run_hip_ad(fields, tl_i, eta, dt, ext, gpu, nx, 137)
+    for n in NL_IN:
+        ad_i[n][(138 if n in ("aph", "lu") else 137):] = 0.0
+    _, _, norm3 = symmetry_norm3(tl_i, fi, ad_i)
+    # oracle verdict per column must be the same as the kernels' verdict
+    _, o_tl_i = run_oracle_tl(fields, fi, eta, dt, ext)
+    _, o_ad_i = run_oracle_ad(fields, o_tl_i, eta, dt, ext)
+    _, _, o_norm3 = symmetry_norm3(o_tl_i, fi, o_ad_i)
+    assert np.array_equal(norm3 < 1e4, o_norm3 < 1e4)
+    assert np.mean(norm3 < 1e4) > 0.95
+    _, ad_i = run_hip_ad(fields, tl_i, eta, dt, externals(NLEV=137, AD_TRAJ_FIX=1), gpu, nx, 137)
+    for n in NL_IN:
+        ad_i[n][(138 if n in ("aph", "lu") else 137):] = 0.0
+    _, _, norm3 = symmetry_norm3(tl_i, fi, ad_i)
+    assert norm3.max() < 1e4, norm3.max()
+    print(f"symmetry test (HIP, AD_TRAJ_FIX): max error {norm3.max():.3e} x eps")
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_increment_and_perturbed_state(gpu, dtype):
+    import torch
+
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd import storage
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.stencils import compile_stencil
+
+    nx, nz = 130, 137
+    fields, _, _ = nl_case(nx, dtype=dtype)
+    dev = to_device(fields, gpu)
+    st = {"in_" + n: dev["in_" + n] for n in INC}
+    for ignore in (False, True):
+        inc = {"out_" + n + "_i": storage.zeros(nx, nz, dtype, gpu) for n in INC}
+        compile_stencil("state_increment", {"IGNORE_SUPSAT": ignore})(
+            **st, **inc, f=dtype(0.01), origin=(0, 0, 0), domain=(nx, 1, nz + 1), validate_args=True,
+            exec_info=None)
+        for n in INC:
+            want = (dtype(0.01) * fields["in_" + n]).astype(dtype)
+            if n == "supsat" and ignore:
+                want = np.zeros_like(want)
+            assert np.array_equal(from_device(inc["out_" + n + "_i"]), want), n  # one multiply: bit-exact
+    out = {"out_" + n: storage.zeros(nx, nz, dtype, gpu) for n in INC}
+    compile_stencil("perturbed_state", {})(
+        **st, **{"in_" + n + "_i": inc["out_" + n + "_i"] for n in INC}, **out, f=dtype(1e-3),
+        origin=(0, 0, 0), domain=(nx, 1, nz + 1), validate_args=True, exec_info=None)
+    torch.cuda.synchronize()
+    for n in INC:
+        xi = from_device(inc["out_" + n + "_i"])
+        want = fields["in_" + n] + dtype(1e-3) * xi
+        got = from_device(out["out_" + n])
+        # a + f*b is contracted to one fma on the GPU: agree to 1 ulp
+        np.testing.assert_allclose(got, want, rtol=4 * np.finfo(dtype).eps, atol=0)
+
+
+def test_tl_ad_reject_evaporation_switch(gpu):
+    """LEVAPLS2 / LDRAIN1D have no TL/AD instantiation: the call must raise, not compute something else."""
+    ext = externals(NLEV=137, LEVAPLS2=True)
+    fields, eta, dt = nl_case(64)
+    with pytest.raises(ValueError, match="LEVAPLS2"):
+        run_hip_tl(fields, increments(fields), eta, dt, ext, gpu, 64, 137)

@@ -1,0 +1,81 @@
+"""CPU checks that pin the oracle's TL and AD restatements relative to its NL restatement - the
+reference's own test strategy: Taylor test (TL vs finite differences of NL,
+tangent_linear/validation.py:150-261) and symmetry test (AD vs TL, adjoint/validation.py:132-215)."""
+import numpy as np
+import pytest
+
+from helpers import (NL_IN, NL_OUT, externals, increments, nl_case, nlev_of, run_oracle_ad, run_oracle_nl,
+                     run_oracle_tl, symmetry_norm3, taylor_norms, taylor_verdict)
+from oracle import cloudsc2_numpy as oracle
+
+F2S = tuple(10.0 ** -i for i in range(1, 11))
+
+
+def test_tl_trajectory_equals_nl():
+    ext = externals(NLEV=137)
+    fields, eta, dt = nl_case(128)
+    nl = run_oracle_nl(fields, eta, dt, ext)
+    tl, _ = run_oracle_tl(fields, increments(fields), eta, dt, ext)
+    for n in NL_OUT:
+        k = nlev_of(n, 137)
+        scale = max(np.abs(nl[n]).max(), 1e-300)
+        assert np.abs(tl[n][:k] - nl[n][:k]).max() <= 1e-12 * scale, n
+
+
+def test_taylor_test_of_the_oracle():
+    """LREGCL = False, factor1 = 0.01, factor2 = 1e-1 .. 1e-10 (drivers/run_taylor_test.py:75-90):
+    every per-field ratio must converge to 1 and the aggregate norm must show the V shape."""
+    ext = externals(LREGCL=False, NLEV=137)
+    fields, eta, dt = nl_case(192)
+    fi = increments(fields, 0.01)
+    nl0 = run_oracle_nl(fields, eta, dt, ext)
+    _, tl_i = run_oracle_tl(fields, fi, eta, dt, ext)
+
+    def nlp(f2):
+        fp = {k: fields[k] + f2 * fi[k + "_i"] for k in fields}
+        return run_oracle_nl(fp, eta, dt, ext)
+
+    norms = taylor_norms(nl0, nlp, tl_i, F2S)
+    err = np.abs(1 - norms)
+    assert err.min() < 1e-6, norms
+    assert err[4:9].max() < 1e-4, norms           # 1e-5 .. 1e-9: linear regime
+    # per-field derivative check at the best step size (stricter than the aggregate norm)
+    f2 = 1e-6
+    p = nlp(f2)
+    for n in NL_OUT:
+        den = f2 * tl_i[n].sum()
+        if abs(den) > 1e-300:
+            assert abs((p[n] - nl0[n]).sum() / den - 1) < 1e-4, n
+
+
+def test_symmetry_test_of_the_oracle():
+    """AD vs TL as the reference's SymmetryTest (pass criterion norm3 < 1e4, adjoint/validation.py:160).
+    With the reference's literal freezing tests (quirks Q4/Q5) the few columns whose saturation
+    adjustment crosses RTT fail; with AD_TRAJ_FIX (the NL/TL tests) EVERY column matches to a few eps,
+    i.e. the AD restatement is the exact transpose of the TL restatement."""
+    fields, eta, dt = nl_case(256)
+    fi = increments(fields, 0.01, ignore_supsat=True)
+    ext = externals(NLEV=137)
+    tl, tl_i = run_oracle_tl(fields, fi, eta, dt, ext)
+    _, ad_i = run_oracle_ad(fields, tl_i, eta, dt, ext)
+    _, _, norm3 = symmetry_norm3(tl_i, fi, ad_i)
+    assert np.mean(norm3 < 1e4) > 0.95, np.mean(norm3 < 1e4)
+    assert np.median(norm3) < 10
+    ad_nl, ad_i = run_oracle_ad(fields, tl_i, eta, dt, externals(NLEV=137, AD_TRAJ_FIX=1))
+    _, _, norm3 = symmetry_norm3(tl_i, fi, ad_i)
+    assert norm3.max() < 100, norm3.max()
+    for n in NL_OUT:   # and the NL outputs AD recomputes equal TL's trajectory
+        k = nlev_of(n, 137)
+        assert np.abs(ad_nl[n][:k] - tl[n][:k]).max() <= 1e-12 * max(np.abs(tl[n]).max(), 1e-300), n
+
+
+def test_increment_and_perturbation():
+    fields, _, _ = nl_case(16)
+    st = {k[3:]: v for k, v in fields.items()}
+    inc = {k + "_i": np.empty_like(v) for k, v in st.items()}
+    oracle.state_increment(st, inc, 0.01, ignore_supsat=True)
+    assert np.all(inc["supsat_i"] == 0) and np.array_equal(inc["t_i"], 0.01 * st["t"])
+    st.update(inc)
+    out = {k: np.empty_like(v) for k, v in fields.items() for k in [k[3:]]}
+    oracle.perturbed_state(st, out, 1e-3)
+    assert np.array_equal(out["q"], st["q"] + 1e-3 * st["q_i"])

@@ -33,6 +33,22 @@ template <> __device__ __forceinline__ float rsqrt_<float>(float x) { return sqr
 template <typename T> __device__ __forceinline__ T rpow(T x, T y);
 template <> __device__ __forceinline__ double rpow<double>(double x, double y) { return pow(x, y); }
 template <> __device__ __forceinline__ float rpow<float>(float x, float y) { return powf(x, y); }
+// Reciprocal by hardware seed + Newton steps (v_rcp_f64 + 4 fma; v_rcp_f32 + 2 fma): <= ~1 ulp, about
+// half the instructions of the IEEE-correct division sequence hipcc emits for `a / b`.  The column
+// kernels are VALU-issue-bound in fp64 (profiles/), so divisions are expressed as x * frcp(y) and
+// reciprocals shared between the expressions that divide by the same quantity.
+template <typename T> __device__ __forceinline__ T frcp(T x);
+template <> __device__ __forceinline__ double frcp<double>(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+template <> __device__ __forceinline__ float frcp<float>(float x) {
+    float r = __builtin_amdgcn_rcpf(x);
+    r = fmaf(fmaf(-x, r, 1.0f), r, r);
+    return r;
+}
 template <typename T> __device__ __forceinline__ T rmin(T a, T b) { return a < b ? a : b; }
 template <typename T> __device__ __forceinline__ T rmax(T a, T b) { return a > b ? a : b; }
 template <typename T> __device__ __forceinline__ T sq(T x) { return x * x; }
@@ -63,6 +79,15 @@ inline Ext<T> make_ext(const Cloudsc2Params& p) {
 #undef CS2_CP
     e.NLEV = p.NLEV;
     return e;
+}
+
+// Pin a wave-uniform value in a VGPR.  The fp64 kernels use ~45 named double constants; together with
+// the 26 field pointers that is far more than the 102 SGPRs of a wave, and hipcc then spills SGPRs to
+// VGPR lanes and pays two v_readlane per 64-bit constant per use.  A constant that lives in a VGPR
+// pair is a plain VALU operand (no extra instruction); at one wave per SIMD there are VGPRs to spare.
+template <typename T>
+__device__ __forceinline__ void pin_vgpr(T& x) {
+    asm volatile("" : "+v"(x));
 }
 
 // ---- field pointer bundles (kernel arguments, by value) --------------------------------------

@@ -55,9 +55,53 @@ struct NLOut {
     T clc, covptot, tnd_q, tnd_t, tnd_ql, tnd_qi, rfln, sfln;
 };
 
-// One level of the forward sweep (:113-388) for one column.
+// Level-independent derived constants (one set per launch, computed on the host in double).
+template <typename T>
+struct NLK {
+    T rdt, ckcodtl, ckcodti, cons2, rgdt, cons3, meltp2, rlcrit, ricrit, rRD, rRCPD, rRLMLT, cormax, fw2;
+};
+
+template <typename T>
+inline NLK<T> make_nlk(const Cloudsc2Params& p, double dt, bool evap) {
+    NLK<T> k;
+    k.rdt = T(1.0 / dt);
+    k.ckcodtl = T(2.0 * p.RKCONV * dt);              // :120
+    k.ckcodti = T(5.0 * p.RKCONV * dt);              // :121
+    k.cons2 = T(1.0 / (p.RG * dt));                  // :122
+    k.rgdt = T(p.RG * dt);
+    k.cons3 = T(p.RLVTT / p.RCPD);                   // :123
+    k.meltp2 = T(p.RTT + 2.0);                       // :124
+    k.rlcrit = T(1.0 / ((evap ? 1.9 : 2.0) * p.RCLCRIT));     // :250-253
+    k.ricrit = T(1.0 / (evap ? 0.0001 : 2.0 * p.RCLCRIT));    // :263-266
+    k.rRD = T(1.0 / p.RD);
+    k.rRCPD = T(1.0 / p.RCPD);
+    k.rRLMLT = T(1.0 / p.RLMLT);
+    k.cormax = T(1.0 / (1.0 - p.RETV * p.ZQMAX));    // 1 / (1 - RETV * esdp) when esdp is clipped at ZQMAX
+    k.fw2 = T(2.0 * 0.17);                           // tanh(u) + 1 = 2 / (1 + exp(-2u)), u = 0.17 (t - RLPTRC)
+    return k;
+}
+
+// One iteration of the saturation adjustment (nonlinear/_stencils/cuadjtqs.py:24-37) with shared
+// reciprocals: r = 1/(t - z4es) serves the exponent and z2s, rap = 1/ap is the caller's.
+template <typename T>
+__device__ __forceinline__ void nl_cuadj_iter(const Ext<T>& e, T rap, T& t, T& q, T z3es, T z4es, T z5alcp,
+                                              T zaldcp) {
+    const T r = frcp<T>(t - z4es);
+    const T foeew = e.R2ES * rexp<T>(z3es * (t - e.RTT) * r);
+    T qsat = rmin<T>(foeew * rap, e.ZQMAX);
+    const T cor = frcp<T>(T(1.0) - e.RETV * qsat);
+    qsat *= cor;
+    const T z2s = z5alcp * r * r;
+    const T cond = (q - qsat) * frcp<T>(T(1.0) + qsat * cor * z2s);
+    t += zaldcp * cond;
+    q -= cond;
+}
+
+// One level of the forward sweep (:113-388) for one column.  Algebraically the reference's
+// statements; divisions are x * frcp(y) with the reciprocals shared (1/zz, 1/(t-R4LES), 1/(t-R4IES),
+// 1/ap, 1/t, 1/dp, 1/clc), 0.545 (tanh(u) + 1) is evaluated as 1.09 / (1 + exp(-2u)).
 template <typename T, bool EVAP, bool LIN>
-__device__ __forceinline__ NLOut<T> nl_level(const Ext<T>& e, const NLIn<T>& x, T eta_k, T scalm,
+__device__ __forceinline__ NLOut<T> nl_level(const Ext<T>& e, const NLK<T>& kc, const NLIn<T>& x, T eta_k, T scalm,
                                              const CrhCol<T>& crh, T dt, T aph_s, NLCarry<T>& c) {
     NLOut<T> o;
     // :104, :115-117 first guess
@@ -65,45 +109,43 @@ __device__ __forceinline__ NLOut<T> nl_level(const Ext<T>& e, const NLIn<T>& x, 
     T q = x.q + dt * x.tq + x.supsat;
     const T ql = x.ql + dt * x.tql;
     const T qi = x.qi + dt * x.tqi;
-    // :120-124
-    const T ckcodtl = T(2.0) * e.RKCONV * dt;
-    const T ckcodti = T(5.0) * e.RKCONV * dt;
-    const T cons2 = T(1.0) / (e.RG * dt);
-    const T cons3 = e.RLVTT / e.RCPD;
-    const T meltp2 = e.RTT + T(2.0);
     // :130-134
     const T dp = x.aph1 - c.aph_k;
+    const T rdp = frcp<T>(dp);
     const T zz = e.RCPD + e.RCPD * e.RVTMP2 * q;
-    const T lfdcp = e.RLMLT / zz;
-    const T lsdcp = e.RLSTT / zz;
-    const T lvdcp = e.RLVTT / zz;
+    const T rzz = frcp<T>(zz);
+    const T lsdcp = e.RLSTT * rzz;
+    const T lvdcp = e.RLVTT * rzz;
     // :141-160 dqs/dT correction factor
-    T fwat, foeew, esdp;
+    const T rl = frcp<T>(t - e.R4LES);
+    const T ri = frcp<T>(t - e.R4IES);
+    const T rap = frcp<T>(x.ap);
+    T fwat, foeew, cor;
     if constexpr (LIN) {
-        T z3es, z4es;
+        T z3es, r4;
         if (t < e.RTT) {
-            fwat = T(0.545) * (rtanh<T>(T(0.17) * (t - e.RLPTRC)) + T(1.0));
+            fwat = T(1.09) * frcp<T>(T(1.0) + rexp<T>(-kc.fw2 * (t - e.RLPTRC)));
             z3es = e.R3IES;
-            z4es = e.R4IES;
+            r4 = ri;
         } else {
             fwat = T(1.0);
             z3es = e.R3LES;
-            z4es = e.R4LES;
+            r4 = rl;
         }
-        foeew = e.R2ES * rexp<T>(z3es * (t - e.RTT) / (t - z4es));
-        esdp = rmin<T>(foeew / x.ap, e.ZQMAX);
+        foeew = e.R2ES * rexp<T>(z3es * (t - e.RTT) * r4);
+        const T esdp = foeew * rap;
+        cor = (esdp > e.ZQMAX) ? kc.cormax : frcp<T>(T(1.0) - e.RETV * esdp);
     } else {
         // f_foealfa / f_foeewm, common/_stencils/fcttre.py:22-46
         fwat = rmin<T>(T(1.0), sq((rmax<T>(e.RTICE, rmin<T>(e.RTWAT, t)) - e.RTICE) * e.RTWAT_RTICE_R));
-        foeew = e.R2ES * (fwat * rexp<T>(e.R3LES * (t - e.RTT) / (t - e.R4LES)) +
-                          (T(1.0) - fwat) * rexp<T>(e.R3IES * (t - e.RTT) / (t - e.R4IES)));
-        esdp = foeew / x.ap;
+        foeew = e.R2ES * (fwat * rexp<T>(e.R3LES * (t - e.RTT) * rl) +
+                          (T(1.0) - fwat) * rexp<T>(e.R3IES * (t - e.RTT) * ri));
+        cor = frcp<T>(T(1.0) - e.RETV * (foeew * rap));
     }
-    const T facw = e.R5LES / sq(t - e.R4LES);
-    const T faci = e.R5IES / sq(t - e.R4IES);
+    const T facw = e.R5LES * rl * rl;
+    const T faci = e.R5IES * ri * ri;
     const T fac = fwat * facw + (T(1.0) - fwat) * faci;
-    const T dqsdtemp = fac * x.qsat / (T(1.0) - e.RETV * esdp);
-    // :163
+    const T dqsdtemp = fac * x.qsat * cor;
     // :166-186
     const T crh2 = crh2_at(crh, eta_k);
     // :189-193
@@ -121,40 +163,41 @@ __device__ __forceinline__ NLOut<T> nl_level(const Ext<T>& e, const NLIn<T>& x, 
     } else {
         const T qpd = qsat - qt;
         const T qcd = qsat - qcrit;
-        clc = T(1.0) - rsqrt_<T>(qpd / (qcd - scalm * (qt - qcrit)));
+        clc = T(1.0) - rsqrt_<T>(qpd * frcp<T>(qcd - scalm * (qt - qcrit)));
         qc = (scalm * qpd + (T(1.0) - scalm) * qcd) * sq(clc);
     }
     // :210-215 convective detrainment
-    const T gdp = e.RG / (x.aph1 - c.aph_k);
+    const T gdp = e.RG * rdp;
     const T lude = dt * x.lude * gdp;
     if (lude >= e.RLMIN && x.lu1 >= e.ZEPS2) {
-        clc += (T(1.0) - clc) * (T(1.0) - rexp<T>(-lude / x.lu1));
+        clc += (T(1.0) - clc) * (T(1.0) - rexp<T>(-lude * frcp<T>(x.lu1)));
         qc += lude;
     }
     // :218-224 compensating subsidence
-    const T rho = x.ap / (e.RD * t);
-    const T rodqsdp = -rho * x.qsat / (x.ap - e.RETV * foeew);
+    const T rt = frcp<T>(t);
+    const T rho = x.ap * rt * kc.rRD;
+    const T rodqsdp = -rho * x.qsat * frcp<T>(x.ap - e.RETV * foeew);
     const T ldcp = fwat * lvdcp + (T(1.0) - fwat) * lsdcp;
-    const T dtdzmo = e.RG * (T(1.0) / e.RCPD - ldcp * rodqsdp) / (T(1.0) + ldcp * dqsdtemp);
+    const T dtdzmo = e.RG * (kc.rRCPD - ldcp * rodqsdp) * frcp<T>(T(1.0) + ldcp * dqsdtemp);
     const T dqsdz = dqsdtemp * dtdzmo - e.RG * rodqsdp;
-    const T dqc = rmin<T>(dt * dqsdz * (x.mfu + x.mfd) / rho, qc);
+    const T rrho = e.RD * t * rap;
+    const T dqc = rmin<T>(dt * dqsdz * (x.mfu + x.mfd) * rrho, qc);
     qc -= dqc;
     // :227-230
     T qlwc = qc * fwat;
     T qiwc = qc * (T(1.0) - fwat);
-    T condl = (qlwc - ql) / dt;
-    T condi = (qiwc - qi) / dt;
+    T condl = (qlwc - ql) * kc.rdt;
+    T condi = (qiwc - qi) * kc.rdt;
     // :234-235 maximum overlap
     c.covptot = rmax<T>(c.covptot, clc);
-    const T covpclr = rmax<T>(c.covptot - clc, T(0.0));
-    // :238-246 melting of incoming snow
+    // :238-246 melting of incoming snow; cons = cons2 * dp / lfdcp = cons2 * dp * zz / RLMLT
     T rfln, sfln;
     if (c.sfl != T(0.0)) {
-        const T cons = cons2 * dp / lfdcp;
-        const T snmlt = rmin<T>(c.sfl, cons * rmax<T>(t - meltp2, T(0.0)));
+        const T cons = kc.cons2 * dp * zz * kc.rRLMLT;
+        const T snmlt = rmin<T>(c.sfl, cons * rmax<T>(t - kc.meltp2, T(0.0)));
         rfln = c.rfl + snmlt;
         sfln = c.sfl - snmlt;
-        t -= snmlt / cons;
+        t -= snmlt * (kc.rgdt * rdp * e.RLMLT * rzz);
     } else {
         rfln = c.rfl;
         sfln = c.sfl;
@@ -162,89 +205,89 @@ __device__ __forceinline__ NLOut<T> nl_level(const Ext<T>& e, const NLIn<T>& x, 
     // :249-272 autoconversion
     T prr = T(0.0), prs = T(0.0);
     if (clc > e.ZEPS2) {
-        const T lcrit = EVAP ? T(1.9) * e.RCLCRIT : T(2.0) * e.RCLCRIT;
-        const T cldl = qlwc / clc;
-        const T dl = ckcodtl * (T(1.0) - rexp<T>(-sq(cldl / lcrit)));
+        const T rclc = frcp<T>(clc);
+        const T cldl = qlwc * rclc;
+        const T dl = kc.ckcodtl * (T(1.0) - rexp<T>(-sq(cldl * kc.rlcrit)));
         prr = qlwc - clc * cldl * rexp<T>(-dl);
         qlwc -= prr;
-        const T icrit = EVAP ? T(0.0001) : T(2.0) * e.RCLCRIT;
-        const T cldi = qiwc / clc;
-        const T di = ckcodti * rexp<T>(T(0.025) * (t - e.RTT)) * (T(1.0) - rexp<T>(-sq(cldi / icrit)));
+        const T cldi = qiwc * rclc;
+        const T di = kc.ckcodti * rexp<T>(T(0.025) * (t - e.RTT)) * (T(1.0) - rexp<T>(-sq(cldi * kc.ricrit)));
         prs = qiwc - clc * cldi * rexp<T>(-di);
         qiwc -= prs;
     }
     // :275-285 new precipitation
-    const T dr = cons2 * dp * (prr + prs);
-    T rfreeze, fwatr;
+    const T dr = kc.cons2 * dp * (prr + prs);
+    T rfreeze;
     if (t < e.RTT) {
-        rfreeze = cons2 * dp * prr;
-        fwatr = T(0.0);
+        rfreeze = kc.cons2 * dp * prr;
+        sfln += dr;
     } else {
         rfreeze = T(0.0);
-        fwatr = T(1.0);
+        rfln += dr;
     }
-    rfln += fwatr * dr;
-    sfln += (T(1.0) - fwatr) * dr;
     // :288-321 precipitation evaporation
     T evapr = T(0.0), evaps = T(0.0);
     o.covptot = T(0.0);
     if constexpr (EVAP) {
+        const T covpclr = rmax<T>(c.covptot - clc, T(0.0));
         const T prtot = rfln + sfln;
         if (prtot > e.ZEPS2 && covpclr > e.ZEPS2) {
-            const T corqs = T(1.0) + cons3 * dqsdtemp;  // :160
-            const T qlim = rmin<T>(q, x.qsat);          // :163
+            const T corqs = T(1.0) + kc.cons3 * dqsdtemp;  // :160
+            const T qlim = rmin<T>(q, x.qsat);             // :163
             T preclr = prtot * covpclr / c.covptot;
             const T qe = x.qsat - (x.qsat - qlim) * covpclr / sq(T(1.0) - clc);
             const T beta = e.RG * e.RPECONS *
                            rpow<T>(rsqrt_<T>(x.ap / aph_s) / T(0.00509) * preclr / covpclr, T(0.5777));
             const T b = dt * beta * (x.qsat - qe) / (T(1.0) + dt * beta * corqs);
-            const T dtgdp = dt * e.RG / (x.aph1 - c.aph_k);
+            const T dtgdp = dt * e.RG * rdp;
             const T dpr = rmin<T>(covpclr * b / dtgdp, preclr);
             preclr -= dpr;
             if (preclr <= T(0.0)) c.covptot = clc;
             o.covptot = c.covptot;
-            evapr = dpr * rfln / prtot;
+            const T rprtot = frcp<T>(prtot);
+            evapr = dpr * rfln * rprtot;
             rfln -= evapr;
-            evaps = dpr * sfln / prtot;
+            evaps = dpr * sfln * rprtot;
             sfln -= evaps;
         }
     }
     // :328-344 first-guess T and q after cloud processes
+    const T ludeh = x.lude * ldcp;  // in_lude * (fwat * lvdcp + (1 - fwat) * lsdcp)
     const T dqdt = -(condl + condi) + (x.lude + evapr + evaps) * gdp;
     const T dtdt = lvdcp * condl + lsdcp * condi -
-                   (lvdcp * evapr + lsdcp * evaps + x.lude * (fwat * lvdcp + (T(1.0) - fwat) * lsdcp) -
-                    (lsdcp - lvdcp) * rfreeze) * gdp;
+                   (lvdcp * evapr + lsdcp * evaps + ludeh - (lsdcp - lvdcp) * rfreeze) * gdp;
     t += dt * dtdt;
     q += dt * dqdt;
     const T qold = q;
-    // :347 saturation adjustment
-    cuadjtqs_nl(e, x.ap, t, q);
+    // :347 saturation adjustment (nonlinear/_stencils/cuadjtqs.py:40-68)
+    {
+        T z3es, z4es, z5alcp, zaldcp;
+        if (t > e.RTT) {
+            z3es = e.R3LES; z4es = e.R4LES; z5alcp = e.R5ALVCP; zaldcp = e.RALVDCP;
+        } else {
+            z3es = e.R3IES; z4es = e.R4IES; z5alcp = e.R5ALSCP; zaldcp = e.RALSDCP;
+        }
+        nl_cuadj_iter(e, rap, t, q, z3es, z4es, z5alcp, zaldcp);
+        nl_cuadj_iter(e, rap, t, q, z3es, z4es, z5alcp, zaldcp);
+    }
     // :350-364
     const T dq = rmax<T>(qold - q, T(0.0));
-    const T dr2 = cons2 * dp * dq;
-    T rfreeze2;
+    const T dr2 = kc.cons2 * dp * dq;
     if (t < e.RTT) {
-        rfreeze2 = fwat * dr2;
-        fwatr = T(0.0);
+        rfreeze += fwat * dr2;
+        condi += dq * kc.rdt;
+        sfln += dr2;
     } else {
-        rfreeze2 = T(0.0);
-        fwatr = T(1.0);
+        condl += dq * kc.rdt;
+        rfln += dr2;
     }
-    const T rn = fwatr * dr2;
-    const T sn = (T(1.0) - fwatr) * dr2;
-    condl += fwatr * dq / dt;
-    condi += (T(1.0) - fwatr) * dq / dt;
-    rfln += rn;
-    sfln += sn;
-    rfreeze += rfreeze2;
     // :367-380 output tendencies
     o.clc = clc;
     o.tnd_q = -(condl + condi) + (x.lude + evapr + evaps) * gdp;
     o.tnd_t = lvdcp * condl + lsdcp * condi -
-              (lvdcp * evapr + lsdcp * evaps + x.lude * (fwat * lvdcp + (T(1.0) - fwat) * lsdcp) -
-               (lsdcp - lvdcp) * rfreeze) * gdp;
-    o.tnd_ql = (qlwc - ql) / dt;
-    o.tnd_qi = (qiwc - qi) / dt;
+              (lvdcp * evapr + lsdcp * evaps + ludeh - (lsdcp - lvdcp) * rfreeze) * gdp;
+    o.tnd_ql = (qlwc - ql) * kc.rdt;
+    o.tnd_qi = (qiwc - qi) * kc.rdt;
     // :383-388
     o.rfln = rfln;
     o.sfln = sfln;
@@ -289,15 +332,24 @@ __device__ __forceinline__ T nl_trpaus(const T* __restrict__ pt, const T* __rest
     return trpaus;
 }
 
-template <typename T, bool EVAP, bool LIN>
+template <typename T, bool EVAP, bool LIN, bool PINK>
 __global__ void __launch_bounds__(kWave)
-nl_kernel(Ext<T> e, int nx, int nz, int64_t ls, CPtrs<T, NL_NUM_IN> in, const T* __restrict__ eta,
+nl_kernel(Ext<T> e, NLK<T> kc, int nx, int nz, int64_t ls, CPtrs<T, NL_NUM_IN> in, const T* __restrict__ eta,
           MPtrs<T, NL_NUM_OUT> out, T dt) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     T* s_eta = reinterpret_cast<T*>(smem_raw);
     T* s_scalm = s_eta + (nz + 1);
     int klo, khi;
     build_level_table<T>(eta, nz, e, s_eta, s_scalm, klo, khi);
+    if constexpr (PINK) {
+        // constants of the level loop -> VGPRs (see pin_vgpr)
+        pin_vgpr(e.RCPD); pin_vgpr(e.RLSTT); pin_vgpr(e.RLVTT); pin_vgpr(e.R4LES); pin_vgpr(e.R4IES);
+        pin_vgpr(e.RTT); pin_vgpr(e.RLPTRC); pin_vgpr(e.R3IES); pin_vgpr(e.R3LES); pin_vgpr(e.R2ES);
+        pin_vgpr(e.ZQMAX); pin_vgpr(e.RETV); pin_vgpr(e.R5LES); pin_vgpr(e.R5IES); pin_vgpr(e.RTICE);
+        pin_vgpr(e.RG); pin_vgpr(e.RD); pin_vgpr(e.R5ALVCP); pin_vgpr(e.RALVDCP); pin_vgpr(e.R5ALSCP);
+        pin_vgpr(e.RALSDCP); pin_vgpr(kc.rdt); pin_vgpr(kc.cons2); pin_vgpr(kc.rRD); pin_vgpr(kc.rRCPD);
+        pin_vgpr(kc.cormax); pin_vgpr(kc.fw2); pin_vgpr(dt);
+    }
 
     const int gcol = blockIdx.x * kWave + threadIdx.x;
     const bool live = gcol < nx;
@@ -329,12 +381,12 @@ nl_kernel(Ext<T> e, int nx, int nz, int64_t ls, CPtrs<T, NL_NUM_IN> in, const T*
         const bool has_b = (k + 1 < nz);
         if (has_b) b = nl_load<T>(in, ls, col, k + 1);
         {
-            const NLOut<T> o = nl_level<T, EVAP, LIN>(e, a, s_eta[k], s_scalm[k], crh, dt, aph_s, c);
+            const NLOut<T> o = nl_level<T, EVAP, LIN>(e, kc, a, s_eta[k], s_scalm[k], crh, dt, aph_s, c);
             if (live) nl_store<T>(out, e, ls, col, k, o);
         }
         if (has_b) {
             if (k + 2 < nz) a = nl_load<T>(in, ls, col, k + 2);
-            const NLOut<T> o = nl_level<T, EVAP, LIN>(e, b, s_eta[k + 1], s_scalm[k + 1], crh, dt, aph_s, c);
+            const NLOut<T> o = nl_level<T, EVAP, LIN>(e, kc, b, s_eta[k + 1], s_scalm[k + 1], crh, dt, aph_s, c);
             if (live) nl_store<T>(out, e, ls, col, k + 1, o);
         }
     }
@@ -353,8 +405,9 @@ int launch_nl(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
     const bool evap = p.LEVAPLS2 || p.LDRAIN1D;
     const bool lin = p.LPHYLIN || p.LDRAIN1D;
     const T tdt = static_cast<T>(dt);
+    const NLK<T> kc = make_nlk<T>(p, dt, evap);
 #define CS2_NL_LAUNCH(EV, LN) \
-    hipLaunchKernelGGL((nl_kernel<T, EV, LN>), grid, block, smem, stream, e, nx, nz, ls, ci, eta, co, tdt)
+    hipLaunchKernelGGL((nl_kernel<T, EV, LN, sizeof(T) == 8>), grid, block, smem, stream, e, kc, nx, nz, ls, ci, eta, co, tdt)
     if (evap && lin) CS2_NL_LAUNCH(true, true);
     else if (evap && !lin) CS2_NL_LAUNCH(true, false);
     else if (!evap && lin) CS2_NL_LAUNCH(false, true);

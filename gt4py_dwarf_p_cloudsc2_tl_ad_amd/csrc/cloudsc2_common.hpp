@@ -49,6 +49,49 @@ template <> __device__ __forceinline__ float frcp<float>(float x) {
     r = fmaf(fmaf(-x, r, 1.0f), r, r);
     return r;
 }
+// exp() for the level loops.  ocml's exp re-materialises its 11 polynomial coefficients into VGPRs
+// on every call (destructive v_fmac form: 2 v_mov per coefficient, ~42 VALU per call); here the
+// coefficients travel as kernel arguments (`ExpK`), stay in registers across the loop and the
+// evaluation is 19 VALU: n = rint(x log2 e), r = x - n ln2 (two-term Cody-Waite), degree-12 Taylor
+// polynomial in Horner form on |r| <= ln2/2 (truncation 3e-17 relative), ldexp.  The argument is
+// clamped to [-746, 710] first (exp(-746) = 0, exp(710) = inf in double): the autoconversion terms
+// exp(-(cld/crit)^2) reach arguments of -1e20, where the Cody-Waite reduction would lose all bits.
+template <typename T>
+struct ExpK {
+    T l2e, ln2h, ln2l, c12, c11, c10, c9, c8, c7, c6, c5, c4, c3;
+};
+template <typename T>
+inline ExpK<T> make_expk() {
+    ExpK<T> k;
+    k.l2e = T(1.4426950408889634);
+    k.ln2h = T(6.93147180369123816490e-01);
+    k.ln2l = T(1.90821492927058770002e-10);
+    k.c12 = T(1.0 / 479001600.0); k.c11 = T(1.0 / 39916800.0); k.c10 = T(1.0 / 3628800.0);
+    k.c9 = T(1.0 / 362880.0); k.c8 = T(1.0 / 40320.0); k.c7 = T(1.0 / 5040.0); k.c6 = T(1.0 / 720.0);
+    k.c5 = T(1.0 / 120.0); k.c4 = T(1.0 / 24.0); k.c3 = T(1.0 / 6.0);
+    return k;
+}
+template <typename T> __device__ __forceinline__ T fexp(const ExpK<T>& k, T x);
+template <> __device__ __forceinline__ double fexp<double>(const ExpK<double>& k, double x) {
+    x = __builtin_fmin(__builtin_fmax(x, -746.0), 710.0);
+    const double n = __builtin_rint(x * k.l2e);
+    double r = __builtin_fma(-n, k.ln2h, x);
+    r = __builtin_fma(-n, k.ln2l, r);
+    double p = __builtin_fma(k.c12, r, k.c11);
+    p = __builtin_fma(p, r, k.c10);
+    p = __builtin_fma(p, r, k.c9);
+    p = __builtin_fma(p, r, k.c8);
+    p = __builtin_fma(p, r, k.c7);
+    p = __builtin_fma(p, r, k.c6);
+    p = __builtin_fma(p, r, k.c5);
+    p = __builtin_fma(p, r, k.c4);
+    p = __builtin_fma(p, r, k.c3);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return __builtin_ldexp(p, static_cast<int>(n));
+}
+template <> __device__ __forceinline__ float fexp<float>(const ExpK<float>&, float x) { return expf(x); }
 template <typename T> __device__ __forceinline__ T rmin(T a, T b) { return a < b ? a : b; }
 template <typename T> __device__ __forceinline__ T rmax(T a, T b) { return a > b ? a : b; }
 template <typename T> __device__ __forceinline__ T sq(T x) { return x * x; }
@@ -88,6 +131,22 @@ inline Ext<T> make_ext(const Cloudsc2Params& p) {
 template <typename T>
 __device__ __forceinline__ void pin_vgpr(T& x) {
     asm volatile("" : "+v"(x));
+}
+
+// Field access by 32-bit BYTE offset from a uniform base pointer: hipcc then emits the
+// `global_load_dwordx2 v, v_off, s[base:base+1]` form (no per-access 64-bit VALU address arithmetic).
+// The launchers guarantee (nz+1) * lev_stride * sizeof(T) < 2^32.
+template <typename T>
+__device__ __forceinline__ T ldg(const T* base, uint32_t boff) {
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + boff);
+}
+template <typename T>
+__device__ __forceinline__ void stg(T* base, uint32_t boff, T v) {
+    *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + boff) = v;
+}
+template <typename T>
+inline bool fits_u32_offsets(int nz, int64_t ls) {
+    return static_cast<uint64_t>(nz + 1) * static_cast<uint64_t>(ls) * sizeof(T) <= 0xFFFFFFFFull;
 }
 
 // ---- field pointer bundles (kernel arguments, by value) --------------------------------------

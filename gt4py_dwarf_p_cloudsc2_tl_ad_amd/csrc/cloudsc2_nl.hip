@@ -15,7 +15,33 @@
 // 1.9*RCLCRIT / 1e-4 thresholds :250-266), LIN = LPHYLIN or LDRAIN1D (:141-155).
 #include "cloudsc2_common.hpp"
 
+// Tuning switches (A/B-tested with profiles/ab_nl.py; the defaults are the fastest measured set).
+#ifndef CS2_NL_FEXP
+#define CS2_NL_FEXP 1   // 1: cs2::fexp (coefficients as kernel arguments), 0: ocml exp
+#endif
+#ifndef CS2_NL_PINK
+#define CS2_NL_PINK 1   // pin the named physical constants in VGPRs (fp64 only)
+#endif
+#ifndef CS2_NL_PREFETCH
+#define CS2_NL_PREFETCH 1   // levels in flight ahead of the one being computed (1 measured best: the
+#endif                      // access pattern, not latency, bounds the kernel - profiles/microbench_stream.hip)
+#ifndef CS2_NL_DIAG
+#define CS2_NL_DIAG 0   // diagnostics only (wrong results): 1 = memory traffic without the physics,
+#endif                  // 2 = physics without HBM traffic (inputs from 2 cached levels, no stores)
+#ifndef CS2_NL_PINX
+#define CS2_NL_PINX 1   // pin the exp coefficients in VGPRs (fp64 only)
+#endif
+
 namespace cs2 {
+
+template <typename T>
+__device__ __forceinline__ T nl_exp(const ExpK<T>& xk, T x) {
+#if CS2_NL_FEXP
+    return fexp<T>(xk, x);
+#else
+    return rexp<T>(x);
+#endif
+}
 
 template <typename T>
 struct NLIn {
@@ -23,25 +49,25 @@ struct NLIn {
 };
 
 template <typename T>
-__device__ __forceinline__ NLIn<T> nl_load(const CPtrs<T, NL_NUM_IN>& in, int64_t ls, int col, int k) {
-    const int64_t o = int64_t(k) * ls + col;
+// `o` = byte offset of (level k, this lane's column); `lsb` = level stride in bytes.
+__device__ __forceinline__ NLIn<T> nl_load(const CPtrs<T, NL_NUM_IN>& in, uint32_t lsb, uint32_t o) {
     NLIn<T> x;
-    x.ap = in.p[NL_IN_AP][o];
-    x.aph1 = in.p[NL_IN_APH][o + ls];
-    x.lu1 = in.p[NL_IN_LU][o + ls];
-    x.lude = in.p[NL_IN_LUDE][o];
-    x.mfd = in.p[NL_IN_MFD][o];
-    x.mfu = in.p[NL_IN_MFU][o];
-    x.q = in.p[NL_IN_Q][o];
-    x.qi = in.p[NL_IN_QI][o];
-    x.ql = in.p[NL_IN_QL][o];
-    x.qsat = in.p[NL_IN_QSAT][o];
-    x.supsat = in.p[NL_IN_SUPSAT][o];
-    x.t = in.p[NL_IN_T][o];
-    x.tq = in.p[NL_IN_TND_CML_Q][o];
-    x.tqi = in.p[NL_IN_TND_CML_QI][o];
-    x.tql = in.p[NL_IN_TND_CML_QL][o];
-    x.tt = in.p[NL_IN_TND_CML_T][o];
+    x.ap = ldg(in.p[NL_IN_AP], o);
+    x.aph1 = ldg(in.p[NL_IN_APH], o + lsb);
+    x.lu1 = ldg(in.p[NL_IN_LU], o + lsb);
+    x.lude = ldg(in.p[NL_IN_LUDE], o);
+    x.mfd = ldg(in.p[NL_IN_MFD], o);
+    x.mfu = ldg(in.p[NL_IN_MFU], o);
+    x.q = ldg(in.p[NL_IN_Q], o);
+    x.qi = ldg(in.p[NL_IN_QI], o);
+    x.ql = ldg(in.p[NL_IN_QL], o);
+    x.qsat = ldg(in.p[NL_IN_QSAT], o);
+    x.supsat = ldg(in.p[NL_IN_SUPSAT], o);
+    x.t = ldg(in.p[NL_IN_T], o);
+    x.tq = ldg(in.p[NL_IN_TND_CML_Q], o);
+    x.tqi = ldg(in.p[NL_IN_TND_CML_QI], o);
+    x.tql = ldg(in.p[NL_IN_TND_CML_QL], o);
+    x.tt = ldg(in.p[NL_IN_TND_CML_T], o);
     return x;
 }
 
@@ -84,10 +110,10 @@ inline NLK<T> make_nlk(const Cloudsc2Params& p, double dt, bool evap) {
 // One iteration of the saturation adjustment (nonlinear/_stencils/cuadjtqs.py:24-37) with shared
 // reciprocals: r = 1/(t - z4es) serves the exponent and z2s, rap = 1/ap is the caller's.
 template <typename T>
-__device__ __forceinline__ void nl_cuadj_iter(const Ext<T>& e, T rap, T& t, T& q, T z3es, T z4es, T z5alcp,
+__device__ __forceinline__ void nl_cuadj_iter(const Ext<T>& e, const ExpK<T>& xk, T rap, T& t, T& q, T z3es, T z4es, T z5alcp,
                                               T zaldcp) {
     const T r = frcp<T>(t - z4es);
-    const T foeew = e.R2ES * rexp<T>(z3es * (t - e.RTT) * r);
+    const T foeew = e.R2ES * nl_exp<T>(xk, z3es * (t - e.RTT) * r);
     T qsat = rmin<T>(foeew * rap, e.ZQMAX);
     const T cor = frcp<T>(T(1.0) - e.RETV * qsat);
     qsat *= cor;
@@ -101,9 +127,18 @@ __device__ __forceinline__ void nl_cuadj_iter(const Ext<T>& e, T rap, T& t, T& q
 // statements; divisions are x * frcp(y) with the reciprocals shared (1/zz, 1/(t-R4LES), 1/(t-R4IES),
 // 1/ap, 1/t, 1/dp, 1/clc), 0.545 (tanh(u) + 1) is evaluated as 1.09 / (1 + exp(-2u)).
 template <typename T, bool EVAP, bool LIN>
-__device__ __forceinline__ NLOut<T> nl_level(const Ext<T>& e, const NLK<T>& kc, const NLIn<T>& x, T eta_k, T scalm,
+__device__ __forceinline__ NLOut<T> nl_level(const Ext<T>& e, const NLK<T>& kc, const ExpK<T>& xk, const NLIn<T>& x, T eta_k, T scalm,
                                              const CrhCol<T>& crh, T dt, T aph_s, NLCarry<T>& c) {
     NLOut<T> o;
+#if CS2_NL_DIAG == 1
+    {
+        const T s1 = x.ap + x.aph1 + x.lu1 + x.lude + x.mfd + x.mfu + x.q + x.qi;
+        const T s2 = x.ql + x.qsat + x.supsat + x.t + x.tq + x.tqi + x.tql + x.tt;
+        o.clc = s1; o.covptot = s2; o.tnd_q = s1 + s2; o.tnd_t = s1 - s2; o.tnd_ql = s1 * s2; o.tnd_qi = s2 - s1;
+        o.rfln = c.rfl + s1; o.sfln = c.sfl + s2; c.rfl = o.rfln; c.sfl = o.sfln; c.aph_k = x.aph1;
+        return o;
+    }
+#endif
     // :104, :115-117 first guess
     T t = x.t + dt * x.tt;
     T q = x.q + dt * x.tq + x.supsat;
@@ -124,7 +159,7 @@ __device__ __forceinline__ NLOut<T> nl_level(const Ext<T>& e, const NLK<T>& kc, 
     if constexpr (LIN) {
         T z3es, r4;
         if (t < e.RTT) {
-            fwat = T(1.09) * frcp<T>(T(1.0) + rexp<T>(-kc.fw2 * (t - e.RLPTRC)));
+            fwat = T(1.09) * frcp<T>(T(1.0) + nl_exp<T>(xk, -kc.fw2 * (t - e.RLPTRC)));
             z3es = e.R3IES;
             r4 = ri;
         } else {
@@ -132,14 +167,14 @@ __device__ __forceinline__ NLOut<T> nl_level(const Ext<T>& e, const NLK<T>& kc, 
             z3es = e.R3LES;
             r4 = rl;
         }
-        foeew = e.R2ES * rexp<T>(z3es * (t - e.RTT) * r4);
+        foeew = e.R2ES * nl_exp<T>(xk, z3es * (t - e.RTT) * r4);
         const T esdp = foeew * rap;
         cor = (esdp > e.ZQMAX) ? kc.cormax : frcp<T>(T(1.0) - e.RETV * esdp);
     } else {
         // f_foealfa / f_foeewm, common/_stencils/fcttre.py:22-46
         fwat = rmin<T>(T(1.0), sq((rmax<T>(e.RTICE, rmin<T>(e.RTWAT, t)) - e.RTICE) * e.RTWAT_RTICE_R));
-        foeew = e.R2ES * (fwat * rexp<T>(e.R3LES * (t - e.RTT) * rl) +
-                          (T(1.0) - fwat) * rexp<T>(e.R3IES * (t - e.RTT) * ri));
+        foeew = e.R2ES * (fwat * nl_exp<T>(xk, e.R3LES * (t - e.RTT) * rl) +
+                          (T(1.0) - fwat) * nl_exp<T>(xk, e.R3IES * (t - e.RTT) * ri));
         cor = frcp<T>(T(1.0) - e.RETV * (foeew * rap));
     }
     const T facw = e.R5LES * rl * rl;
@@ -170,7 +205,7 @@ __device__ __forceinline__ NLOut<T> nl_level(const Ext<T>& e, const NLK<T>& kc, 
     const T gdp = e.RG * rdp;
     const T lude = dt * x.lude * gdp;
     if (lude >= e.RLMIN && x.lu1 >= e.ZEPS2) {
-        clc += (T(1.0) - clc) * (T(1.0) - rexp<T>(-lude * frcp<T>(x.lu1)));
+        clc += (T(1.0) - clc) * (T(1.0) - nl_exp<T>(xk, -lude * frcp<T>(x.lu1)));
         qc += lude;
     }
     // :218-224 compensating subsidence
@@ -207,12 +242,12 @@ __device__ __forceinline__ NLOut<T> nl_level(const Ext<T>& e, const NLK<T>& kc, 
     if (clc > e.ZEPS2) {
         const T rclc = frcp<T>(clc);
         const T cldl = qlwc * rclc;
-        const T dl = kc.ckcodtl * (T(1.0) - rexp<T>(-sq(cldl * kc.rlcrit)));
-        prr = qlwc - clc * cldl * rexp<T>(-dl);
+        const T dl = kc.ckcodtl * (T(1.0) - nl_exp<T>(xk, -sq(cldl * kc.rlcrit)));
+        prr = qlwc - clc * cldl * nl_exp<T>(xk, -dl);
         qlwc -= prr;
         const T cldi = qiwc * rclc;
-        const T di = kc.ckcodti * rexp<T>(T(0.025) * (t - e.RTT)) * (T(1.0) - rexp<T>(-sq(cldi * kc.ricrit)));
-        prs = qiwc - clc * cldi * rexp<T>(-di);
+        const T di = kc.ckcodti * nl_exp<T>(xk, T(0.025) * (t - e.RTT)) * (T(1.0) - nl_exp<T>(xk, -sq(cldi * kc.ricrit)));
+        prs = qiwc - clc * cldi * nl_exp<T>(xk, -di);
         qiwc -= prs;
     }
     // :275-285 new precipitation
@@ -267,8 +302,8 @@ __device__ __forceinline__ NLOut<T> nl_level(const Ext<T>& e, const NLK<T>& kc, 
         } else {
             z3es = e.R3IES; z4es = e.R4IES; z5alcp = e.R5ALSCP; zaldcp = e.RALSDCP;
         }
-        nl_cuadj_iter(e, rap, t, q, z3es, z4es, z5alcp, zaldcp);
-        nl_cuadj_iter(e, rap, t, q, z3es, z4es, z5alcp, zaldcp);
+        nl_cuadj_iter(e, xk, rap, t, q, z3es, z4es, z5alcp, zaldcp);
+        nl_cuadj_iter(e, xk, rap, t, q, z3es, z4es, z5alcp, zaldcp);
     }
     // :350-364
     const T dq = rmax<T>(qold - q, T(0.0));
@@ -298,32 +333,32 @@ __device__ __forceinline__ NLOut<T> nl_level(const Ext<T>& e, const NLK<T>& kc, 
 }
 
 template <typename T>
-__device__ __forceinline__ void nl_store(const MPtrs<T, NL_NUM_OUT>& out, const Ext<T>& e, int64_t ls,
-                                         int col, int k, const NLOut<T>& o) {
-    const int64_t i = int64_t(k) * ls + col;
-    out.p[NL_OUT_CLC][i] = o.clc;
-    out.p[NL_OUT_COVPTOT][i] = o.covptot;
-    out.p[NL_OUT_TND_Q][i] = o.tnd_q;
-    out.p[NL_OUT_TND_T][i] = o.tnd_t;
-    out.p[NL_OUT_TND_QL][i] = o.tnd_ql;
-    out.p[NL_OUT_TND_QI][i] = o.tnd_qi;
+__device__ __forceinline__ void nl_store(const MPtrs<T, NL_NUM_OUT>& out, const Ext<T>& e, uint32_t lsb, uint32_t i,
+                                         const NLOut<T>& o) {
+    stg(out.p[NL_OUT_CLC], i, o.clc);
+    stg(out.p[NL_OUT_COVPTOT], i, o.covptot);
+    stg(out.p[NL_OUT_TND_Q], i, o.tnd_q);
+    stg(out.p[NL_OUT_TND_T], i, o.tnd_t);
+    stg(out.p[NL_OUT_TND_QL], i, o.tnd_ql);
+    stg(out.p[NL_OUT_TND_QI], i, o.tnd_qi);
     // :391-399 fluxes leave level k through half level k+1
-    out.p[NL_OUT_FPLSL][i + ls] = o.rfln;
-    out.p[NL_OUT_FPLSN][i + ls] = o.sfln;
-    out.p[NL_OUT_FHPSL][i + ls] = -o.rfln * e.RLVTT;
-    out.p[NL_OUT_FHPSN][i + ls] = -o.sfln * e.RLSTT;
+    stg(out.p[NL_OUT_FPLSL], i + lsb, o.rfln);
+    stg(out.p[NL_OUT_FPLSN], i + lsb, o.sfln);
+    stg(out.p[NL_OUT_FHPSL], i + lsb, -o.rfln * e.RLVTT);
+    stg(out.p[NL_OUT_FHPSN], i + lsb, -o.sfln * e.RLSTT);
 }
 
 // Tropopause pre-scan (:107-111): eta of the LAST level k in the window with t[k] > t[k+1].
 template <typename T>
-__device__ __forceinline__ T nl_trpaus(const T* __restrict__ pt, const T* __restrict__ ptt, int64_t ls,
-                                       int col, T dt, const T* s_eta, int klo, int khi) {
+__device__ __forceinline__ T nl_trpaus(const T* __restrict__ pt, const T* __restrict__ ptt, uint32_t lsb,
+                                       uint32_t colb, T dt, const T* s_eta, int klo, int khi) {
     T trpaus = T(0.1);
     if (klo <= khi) {
-        T tk = pt[int64_t(klo) * ls + col] + dt * ptt[int64_t(klo) * ls + col];
+        uint32_t o = uint32_t(klo) * lsb + colb;
+        T tk = ldg(pt, o) + dt * ldg(ptt, o);
         for (int k = klo; k <= khi; ++k) {
-            const int64_t o1 = int64_t(k + 1) * ls + col;
-            const T tk1 = pt[o1] + dt * ptt[o1];
+            o += lsb;
+            const T tk1 = ldg(pt, o) + dt * ldg(ptt, o);
             const T ek = s_eta[k];
             if (ek > T(0.1) && ek < T(0.4) && tk > tk1) trpaus = ek;
             tk = tk1;
@@ -334,14 +369,14 @@ __device__ __forceinline__ T nl_trpaus(const T* __restrict__ pt, const T* __rest
 
 template <typename T, bool EVAP, bool LIN, bool PINK>
 __global__ void __launch_bounds__(kWave)
-nl_kernel(Ext<T> e, NLK<T> kc, int nx, int nz, int64_t ls, CPtrs<T, NL_NUM_IN> in, const T* __restrict__ eta,
+nl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, NL_NUM_IN> in, const T* __restrict__ eta,
           MPtrs<T, NL_NUM_OUT> out, T dt) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     T* s_eta = reinterpret_cast<T*>(smem_raw);
     T* s_scalm = s_eta + (nz + 1);
     int klo, khi;
     build_level_table<T>(eta, nz, e, s_eta, s_scalm, klo, khi);
-    if constexpr (PINK) {
+    if constexpr (PINK && CS2_NL_PINK) {
         // constants of the level loop -> VGPRs (see pin_vgpr)
         pin_vgpr(e.RCPD); pin_vgpr(e.RLSTT); pin_vgpr(e.RLVTT); pin_vgpr(e.R4LES); pin_vgpr(e.R4IES);
         pin_vgpr(e.RTT); pin_vgpr(e.RLPTRC); pin_vgpr(e.R3IES); pin_vgpr(e.R3LES); pin_vgpr(e.R2ES);
@@ -350,12 +385,27 @@ nl_kernel(Ext<T> e, NLK<T> kc, int nx, int nz, int64_t ls, CPtrs<T, NL_NUM_IN> i
         pin_vgpr(e.RALSDCP); pin_vgpr(kc.rdt); pin_vgpr(kc.cons2); pin_vgpr(kc.rRD); pin_vgpr(kc.rRCPD);
         pin_vgpr(kc.cormax); pin_vgpr(kc.fw2); pin_vgpr(dt);
     }
+    if constexpr (PINK && CS2_NL_PINX && CS2_NL_FEXP) {
+        pin_vgpr(xk.l2e); pin_vgpr(xk.ln2h); pin_vgpr(xk.ln2l); pin_vgpr(xk.c12); pin_vgpr(xk.c11);
+        pin_vgpr(xk.c10); pin_vgpr(xk.c9); pin_vgpr(xk.c8); pin_vgpr(xk.c7); pin_vgpr(xk.c6);
+        pin_vgpr(xk.c5); pin_vgpr(xk.c4); pin_vgpr(xk.c3);
+    }
 
     const int gcol = blockIdx.x * kWave + threadIdx.x;
+#if CS2_NL_DIAG == 2
+    const bool live = gcol < nx && nz < 0;   // never true at run time: no stores
+#else
     const bool live = gcol < nx;
-    const int col = live ? gcol : nx - 1;  // dead lanes shadow the last column, stores masked
+#endif
+    const int col = (gcol < nx) ? gcol : nx - 1;  // dead lanes shadow the last column, stores masked
+#if CS2_NL_DIAG == 2
+    const uint32_t lsb = 0;                  // every level reads level 0 (cache-resident)
+#else
+    const uint32_t lsb = uint32_t(ls) * uint32_t(sizeof(T));
+#endif
+    const uint32_t colb = uint32_t(col) * uint32_t(sizeof(T));
 
-    const T trpaus = nl_trpaus<T>(in.p[NL_IN_T], in.p[NL_IN_TND_CML_T], ls, col, dt, s_eta, klo, khi);
+    const T trpaus = nl_trpaus<T>(in.p[NL_IN_T], in.p[NL_IN_TND_CML_T], lsb, colb, dt, s_eta, klo, khi);
     const CrhCol<T> crh = crh_setup<T>(trpaus);
 
     // :93-100
@@ -363,31 +413,37 @@ nl_kernel(Ext<T> e, NLK<T> kc, int nx, int nz, int64_t ls, CPtrs<T, NL_NUM_IN> i
     c.rfl = T(0.0);
     c.sfl = T(0.0);
     c.covptot = T(0.0);
-    c.aph_k = in.p[NL_IN_APH][col];
-    const T aph_s = EVAP ? in.p[NL_IN_APH][int64_t(nz) * ls + col] : T(1.0);
+    c.aph_k = ldg(in.p[NL_IN_APH], colb);
+    const T aph_s = EVAP ? ldg(in.p[NL_IN_APH], uint32_t(nz) * lsb + colb) : T(1.0);
 
     if (live) {
         // top half level: no flux enters the column (:392-394; out_fpls*[0] written as 0, the
         // value the reference relies on from zero-initialised storage - SURVEY.md App. B Q2)
-        out.p[NL_OUT_FPLSL][col] = T(0.0);
-        out.p[NL_OUT_FPLSN][col] = T(0.0);
-        out.p[NL_OUT_FHPSL][col] = T(0.0);
-        out.p[NL_OUT_FHPSN][col] = T(0.0);
+        stg(out.p[NL_OUT_FPLSL], colb, T(0.0));
+        stg(out.p[NL_OUT_FPLSN], colb, T(0.0));
+        stg(out.p[NL_OUT_FHPSL], colb, T(0.0));
+        stg(out.p[NL_OUT_FHPSN], colb, T(0.0));
     }
 
-    NLIn<T> a = nl_load<T>(in, ls, col, 0);
-    NLIn<T> b = a;
-    for (int k = 0; k < nz; k += 2) {
-        const bool has_b = (k + 1 < nz);
-        if (has_b) b = nl_load<T>(in, ls, col, k + 1);
-        {
-            const NLOut<T> o = nl_level<T, EVAP, LIN>(e, kc, a, s_eta[k], s_scalm[k], crh, dt, aph_s, c);
-            if (live) nl_store<T>(out, e, ls, col, k, o);
-        }
-        if (has_b) {
-            if (k + 2 < nz) a = nl_load<T>(in, ls, col, k + 2);
-            const NLOut<T> o = nl_level<T, EVAP, LIN>(e, kc, b, s_eta[k + 1], s_scalm[k + 1], crh, dt, aph_s, c);
-            if (live) nl_store<T>(out, e, ls, col, k + 1, o);
+    // Level sweep with a software prefetch ring of depth PD: while level k is computed, the inputs
+    // of levels k+1 .. k+PD are in flight (one wave per SIMD at 65 536 columns: HBM latency can only
+    // hide behind this wave's own work, and ~1.6 us x 8 TB/s / 1024 waves wants > 1 level in flight).
+    constexpr int PD = CS2_NL_PREFETCH;
+    NLIn<T> buf[PD + 1];
+#pragma unroll
+    for (int j = 0; j < PD; ++j) buf[j] = nl_load<T>(in, lsb, colb + uint32_t(j < nz ? j : 0) * lsb);
+    buf[PD] = buf[0];
+    uint32_t o = colb;  // byte offset of (level k, column)
+    for (int k0 = 0; k0 < nz; k0 += PD + 1) {
+#pragma unroll
+        for (int j = 0; j <= PD; ++j) {
+            const int k = k0 + j;
+            if (k < nz) {
+                if (k + PD < nz) buf[(j + PD) % (PD + 1)] = nl_load<T>(in, lsb, o + uint32_t(PD) * lsb);
+                const NLOut<T> r = nl_level<T, EVAP, LIN>(e, kc, xk, buf[j], s_eta[k], s_scalm[k], crh, dt, aph_s, c);
+                if (live) nl_store<T>(out, e, lsb, o, r);
+                o += lsb;
+            }
         }
     }
 }
@@ -406,8 +462,10 @@ int launch_nl(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
     const bool lin = p.LPHYLIN || p.LDRAIN1D;
     const T tdt = static_cast<T>(dt);
     const NLK<T> kc = make_nlk<T>(p, dt, evap);
+    const ExpK<T> xk = make_expk<T>();
+    if (!fits_u32_offsets<T>(nz, ls)) return -2;
 #define CS2_NL_LAUNCH(EV, LN) \
-    hipLaunchKernelGGL((nl_kernel<T, EV, LN, sizeof(T) == 8>), grid, block, smem, stream, e, kc, nx, nz, ls, ci, eta, co, tdt)
+    hipLaunchKernelGGL((nl_kernel<T, EV, LN, sizeof(T) == 8>), grid, block, smem, stream, e, kc, xk, nx, nz, ls, ci, eta, co, tdt)
     if (evap && lin) CS2_NL_LAUNCH(true, true);
     else if (evap && !lin) CS2_NL_LAUNCH(true, false);
     else if (!evap && lin) CS2_NL_LAUNCH(false, true);

@@ -25,10 +25,13 @@ computation (and read as 0 where never assigned).
 
 Array layout: ``a[k, col]`` with nz+1 levels (`interval(0, -1)` = k in [0, nz)).
 
-PARITY PINNING.  `data/input.h5` is absent, so the golden files pin only layout and invariants
-(tests/test_golden_invariants.py).  The formulas are pinned by executing the reference's own
-stencil source through the build's small gtscript interpreter (tests/golden/…), by
-the TL Taylor test against NL and by the AD dot-product test against TL.
+PARITY PINNING.  `data/input.h5` is absent, so the reference's golden HDF5 files pin only layout and
+invariants (tests/test_golden_invariants.py): parity against data/reference_{double,single}.h5 is
+UNPINNED.  The formulas are pinned instead by the reference's own source: tests/golden/
+reference_exec.npz holds the outputs of the unmodified reference stencils executed by the build's
+gtscript executor (tests/golden/gtscript_exec.py, make_reference_exec.py) on seeded columns, and this
+module reproduces them BIT FOR BIT (tests/test_reference_exec.py; one AD field to 1 ulp) - plus the
+TL Taylor test against NL and the AD dot-product test against TL (tests/test_oracle_consistency.py).
 """
 from __future__ import annotations
 

@@ -1,0 +1,143 @@
+"""Generate golden vectors by executing the REFERENCE's own stencil source (read from
+/root/reference, never copied) through tests/golden/gtscript_exec.py on seeded synthetic columns.
+
+Run in the build container only:  python tests/golden/make_reference_exec.py
+Writes tests/golden/reference_exec.npz (inputs + outputs; data only).  The GPU box has no
+/root/reference, so the tests read the .npz.
+
+What the vectors pin: saturation, cloudsc2_nl (driver flags, and LEVAPLS2=True), cloudsc2_tl
+(LREGCL True/False), cloudsc2_ad (LREGCL True), state_increment, perturbed_state - i.e. every stencil
+the three drivers call - under the executor's reading of gtscript semantics (module docstring there)
+and the provisional parameter set (params.default_externals()).
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+from gtscript_exec import Executor, load_definitions, reference_stencil_files  # noqa: E402
+
+from gt4py_dwarf_p_cloudsc2_tl_ad_amd.params import DEFAULT_TIMESTEP_S, default_externals  # noqa: E402
+from gt4py_dwarf_p_cloudsc2_tl_ad_amd.synthetic import eta_levels, make_state  # noqa: E402
+
+REFERENCE = "/root/reference"
+NX, NZ, SEED = 40, 137, 20240807
+NL_IN = ("ap", "aph", "lu", "lude", "mfd", "mfu", "q", "qi", "ql", "qsat", "supsat", "t",
+         "tnd_cml_q", "tnd_cml_qi", "tnd_cml_ql", "tnd_cml_t")
+NL_OUT = ("clc", "covptot", "fhpsl", "fhpsn", "fplsl", "fplsn", "tnd_q", "tnd_qi", "tnd_ql", "tnd_t")
+
+
+def zeros(nx=NX):
+    return np.zeros((NZ + 1, nx))
+
+
+def main():
+    defs = load_definitions(reference_stencil_files(REFERENCE))
+    ext = default_externals()
+    ext["NLEV"] = NZ
+    dt = DEFAULT_TIMESTEP_S
+    s = make_state(NX, NZ, seed=SEED)
+    eta = eta_levels(NZ, seed=SEED)
+    out = {"eta": eta, "dt": np.float64(dt), "nz": np.int64(NZ)}
+    ins = {"in_" + k[2:]: v.copy() for k, v in s.items()}
+
+    # saturation (domain nz levels; kflag=1, lphylin=True as the drivers)
+    qsat = zeros()
+    Executor(defs, {**ext, "KFLAG": 1, "LPHYLIN": True, "QMAX": 0.5}).run(
+        "saturation", {"in_ap": ins["in_ap"], "in_t": ins["in_t"], "out_qsat": qsat}, {}, NZ, domain_levels=NZ)
+    ins["in_qsat"] = qsat
+    for n in NL_IN:
+        out["in_" + n] = ins["in_" + n]
+
+    def ij():
+        return np.zeros(NX)
+
+    def run_nl(e, inputs):
+        f = {k: v.copy() for k, v in inputs.items()}
+        f["in_eta"] = eta
+        for n in NL_OUT:
+            f["out_" + n] = zeros()
+        for n in ("tmp_aph_s", "tmp_covptot", "tmp_rfl", "tmp_sfl", "tmp_trpaus"):
+            f[n] = ij()
+        Executor(defs, e).run("cloudsc2_nl", f, {"dt": dt}, NZ)
+        return {n: f["out_" + n] for n in NL_OUT}
+
+    for tag, e in (("nl", ext), ("nl_evap", {**ext, "LEVAPLS2": True}), ("nl_nolin", {**ext, "LPHYLIN": False})):
+        r = run_nl(e, ins)
+        for n in NL_OUT:
+            out[f"{tag}_out_{n}"] = r[n]
+
+    # state_increment (f = 0.01) and perturbed_state (f = 1e-3)
+    INC = ("aph", "ap", "q", "qsat", "t", "ql", "qi", "lude", "lu", "mfu", "mfd",
+           "tnd_cml_t", "tnd_cml_q", "tnd_cml_ql", "tnd_cml_qi", "supsat")
+    for tag, ign in (("inc", False), ("inc_nosupsat", True)):
+        f = {"in_" + n: ins["in_" + n].copy() for n in INC}
+        f.update({"out_" + n + "_i": zeros() for n in INC})
+        Executor(defs, {"IGNORE_SUPSAT": ign}).run("state_increment", f, {"f": 0.01}, NZ)
+        for n in INC:
+            out[f"{tag}_{n}_i"] = f["out_" + n + "_i"]
+    f = {"in_" + n: ins["in_" + n].copy() for n in INC}
+    f.update({"in_" + n + "_i": out[f"inc_{n}_i"].copy() for n in INC})
+    f.update({"out_" + n: zeros() for n in INC})
+    Executor(defs, {}).run("perturbed_state", f, {"f": 1e-3}, NZ)
+    for n in INC:
+        out[f"pert_{n}"] = f["out_" + n]
+
+    klevel = np.arange(0, NZ + 1)
+
+    def run_tl(e, inc_tag):
+        f = {k: v.copy() for k, v in ins.items()}
+        f.update({"in_" + n + "_i": out[f"{inc_tag}_{n}_i"].copy() for n in NL_IN})
+        f["in_eta"] = eta
+        f["tmp_klevel"] = klevel
+        for n in NL_OUT:
+            f["out_" + n] = zeros()
+            f["out_" + n + "_i"] = zeros()
+        for n in ("tmp_aph_s", "tmp_aph_s_i", "tmp_covptot", "tmp_covptot_i", "tmp_rfl", "tmp_rfl_i", "tmp_sfl",
+                  "tmp_sfl_i", "tmp_trpaus"):
+            f[n] = ij()
+        Executor(defs, e).run("cloudsc2_tl", f, {"dt": dt}, NZ)
+        return f
+
+    evap = {**ext, "LEVAPLS2": True}
+    for tag, e, inc_tag in (("tl", ext, "inc"), ("tl_noreg", {**ext, "LREGCL": False}, "inc"),
+                            ("tl_sym", ext, "inc_nosupsat"), ("tl_evap", evap, "inc_nosupsat")):
+        f = run_tl(e, inc_tag)
+        for n in NL_OUT:
+            out[f"{tag}_out_{n}"] = f["out_" + n]
+            out[f"{tag}_out_{n}_i"] = f["out_" + n + "_i"]
+
+    # cloudsc2_ad forced with the TL outputs of the symmetry-test setup (adjoint/validation.py:132-153)
+    # (no AD vector with LEVAPLS2: on these columns the reference's own TL evaporation block already
+    #  produces perturbations of order 1e43 - "the code never enters this branch when input data are
+    #  retrieved from input.h5", tangent_linear/_stencils/cloudsc2.py:529-530 - so its adjoint is noise)
+    for tag, e, tl_tag in (("ad", ext, "tl_sym"), ("ad_noreg", {**ext, "LREGCL": False}, "tl_sym")):
+        f = {k: v.copy() for k, v in ins.items()}
+        f["in_eta"] = eta
+        f["tmp_klevel"] = klevel
+        for n in NL_OUT:
+            f["in_" + n + "_i"] = out[f"{tl_tag}_out_{n}_i"].copy()
+            f["out_" + n] = zeros()
+        for n in NL_IN:
+            f["out_" + n + "_i"] = zeros()
+        for n in ("tmp_aph_s", "tmp_aph_s_i", "tmp_covptotp", "tmp_rfln", "tmp_rfln_i", "tmp_sfln", "tmp_sfln_i",
+                  "tmp_trpaus"):
+            f[n] = ij()
+        Executor(defs, e).run("cloudsc2_ad", f, {"dt": dt}, NZ)
+        for n in NL_OUT:
+            out[f"{tag}_out_{n}"] = f["out_" + n]
+        for n in NL_IN:
+            out[f"{tag}_out_{n}_i"] = f["out_" + n + "_i"]
+
+    path = os.path.join(HERE, "reference_exec.npz")
+    np.savez_compressed(path, **out)
+    print(path, len(out), "arrays", os.path.getsize(path) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

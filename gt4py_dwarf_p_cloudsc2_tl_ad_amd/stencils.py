@@ -284,6 +284,8 @@ def finalize_exec_info(exec_info: Optional[dict]) -> None:
     """Resolve the recorded HIP events into `total_run_time` (seconds) per stencil."""
     if not exec_info:
         return
+    if not any(isinstance(r, dict) and r.get("events") for r in exec_info.values()):
+        return
     torch.cuda.synchronize()
     for rec in exec_info.values():
         if isinstance(rec, dict) and "events" in rec:

@@ -1,0 +1,156 @@
+"""Shared set-up of the three drivers: options, configuration, grid, state, parameters
+(the part of /root/reference/drivers/run_nonlinear.py:51-94 that all drivers repeat)."""
+from __future__ import annotations
+
+import argparse
+import os
+from datetime import datetime, timedelta
+from typing import Any, Dict, Tuple
+
+import numpy as np
+import torch
+
+from ..framework.config import DataTypes, GridConfig, GT4PyConfig, IOConfig, PythonConfig
+from ..framework.fields import DataArray
+from ..framework.grid import ComputationalGrid, I, J, K
+from ..framework.iox import HDF5GridOperator, HDF5Operator
+from ..framework.backends import backend_device
+from ..params import default_externals
+from ..physics import EtaLevels
+from .. import storage, synthetic
+
+DATA_DIR = os.environ.get("CLOUDSC2_DATA_DIR", "/root/reference/data")
+
+_STATE_H5 = {  # state name -> (HDF5 dataset, species index or None, half-level?)   (setup.py:48-65)
+    "f_ap": ("PAP", None, False), "f_aph": ("PAPH", None, True), "f_lu": ("PLU", None, False),
+    "f_lude": ("PLUDE", None, False), "f_mfd": ("PMFD", None, False), "f_mfu": ("PMFU", None, False),
+    "f_qi": ("PCLV", 1, False), "f_ql": ("PCLV", 0, False), "f_q": ("PQ", None, False),
+    "f_supsat": ("PSUPSAT", None, False), "f_t": ("PT", None, False),
+    "f_tnd_cml_qi": ("TENDENCY_CML_CLD", 1, False), "f_tnd_cml_ql": ("TENDENCY_CML_CLD", 0, False),
+    "f_tnd_cml_q": ("TENDENCY_CML_Q", None, False), "f_tnd_cml_t": ("TENDENCY_CML_T", None, False),
+}
+# parameter groups = the reference's pydantic models (iox.py:25-209), restricted to what the stencils import
+_PARAM_GROUPS = {
+    "yoethf": ("R2ES", "R3IES", "R3LES", "R4IES", "R4LES", "R5ALSCP", "R5ALVCP", "R5IES", "R5LES", "RALFDCP",
+               "RALSDCP", "RALVDCP", "RKOOP1", "RKOOP2", "RTICE", "RTICECU", "RTWAT", "RTWAT_RTICECU_R",
+               "RTWAT_RTICE_R", "RVTMP2"),
+    "yomcst": ("RCPD", "RD", "RETV", "RG", "RLMLT", "RLSTT", "RLVTT", "RTT", "RV"),
+    "yrecldp": ("RLMIN", "RKCONV", "RCLCRIT", "RPECONS"),
+    "yrephli": ("RLPTRC", "LPHYLIN"),
+    "yrncl": ("LREGCL",),
+    "yrphnc": ("LEVAPLS2",),
+}
+
+
+def add_common_options(ap: argparse.ArgumentParser) -> None:
+    ap.add_argument("--backend", default="hip", help="stencil backend (this build provides: hip)")
+    ap.add_argument("--enable-checks", dest="enable_checks", action="store_true", default=False)
+    ap.add_argument("--disable-checks", dest="enable_checks", action="store_false")
+    ap.add_argument("--enable-validation", dest="enable_validation", action="store_true", default=True)
+    ap.add_argument("--disable-validation", dest="enable_validation", action="store_false")
+    ap.add_argument("--num-cols", type=int, default=1)
+    ap.add_argument("--num-runs", type=int, default=1)
+    ap.add_argument("--precision", default="double", choices=["double", "single"])
+    ap.add_argument("--host-alias", default=None)
+    ap.add_argument("--output-csv-file", default=None)
+    ap.add_argument("--output-csv-file-stencils", default=None)
+    ap.add_argument("--input", default="auto",
+                    help="'auto': <data dir>/input.h5 if readable, else its 100-column synthetic stand-in, tiled "
+                         "to --num-cols like the real file; 'synthetic': --num-cols DISTINCT seeded columns "
+                         "(mixed regimes) generated on the device")
+
+
+def make_config(args) -> Tuple[PythonConfig, IOConfig]:
+    cfg = PythonConfig(
+        num_cols=args.num_cols, enable_validation=args.enable_validation,
+        input_file=os.path.join(DATA_DIR, "input.h5"), num_runs=args.num_runs, precision="double",
+        data_types=DataTypes(bool=bool, float=np.float64, int=np.int64),
+        gt4py_config=GT4PyConfig(backend=args.backend, rebuild=False, validate_args=True, verbose=True),
+        sympl_enable_checks=True,
+    ).with_precision(args.precision).with_backend(args.backend).with_checks(args.enable_checks)
+    cfg = cfg.with_validation(args.enable_validation, getattr(args, "atol", None), getattr(args, "rtol", None))
+    io = IOConfig(output_csv_file=None, host_name="").with_output_csv_file(args.output_csv_file) \
+        .with_host_name(args.host_alias)
+    return cfg, io
+
+
+def _groups_from_defaults() -> Dict[str, Dict[str, Any]]:
+    ext = default_externals()
+    return {g: {k: ext[k] for k in keys} for g, keys in _PARAM_GROUPS.items()}
+
+
+def setup(args) -> Dict[str, Any]:
+    """Grid, state (with f_eta), timestep and parameter groups.  Input source: see `--input`."""
+    cfg, io = make_config(args)
+    gcfg = cfg.gt4py_config
+    device = backend_device(gcfg)
+    # "auto": the reader path (real input.h5 if readable, otherwise the 100-column synthetic stand-in
+    # dataset of framework.iox, tiled to --num-cols exactly as the real file would be)
+    use_file = args.input == "auto"
+    if use_file:
+        op = HDF5Operator(cfg.input_file, gt4py_config=gcfg)
+        nz = int(np.asarray(op.f["KLEV"]).reshape(-1)[0])
+        nx = cfg.num_cols or int(np.asarray(op.f["KLON"]).reshape(-1)[0])
+        grid = ComputationalGrid(GridConfig(nx=nx, ny=1, nz=nz))
+        gop = HDF5GridOperator(cfg.input_file, grid, gt4py_config=gcfg)
+        state: Dict[str, Any] = {}
+        for name, (h5, idx, half) in _STATE_H5.items():
+            kdim = K - 1 / 2 if half else K
+            from ..framework.grid import D5, IJ, ExpandedDim
+            dims_map = (IJ, ExpandedDim, kdim) if idx is None else (IJ, ExpandedDim, K, D5[idx])
+            h5_dims = (kdim, IJ) if idx is None else (D5, K, IJ)
+            state[name] = gop.get_field((I, J, kdim), "float", "", h5, h5_dims, dims_map)
+        dt = timedelta(seconds=float(np.asarray(op.f["PTSPHY"]).reshape(-1)[0]))
+        names = {k: np.asarray(op.f[k]).reshape(-1)[0] for k in op.f.keys() if np.asarray(op.f[k]).size == 1}
+        base = default_externals()
+        groups = _groups_from_defaults()
+        for k, v in names.items():
+            key = k.split("_", 1)[1] if k.startswith(("YRECLDP_", "YREPHLI_")) else k
+            for g, keys in _PARAM_GROUPS.items():
+                if key in keys:
+                    groups[g][key] = type(base[key])(v)
+        real = os.path.exists(cfg.input_file) and not type(op.f).__name__ == "_Defaulting"
+        source = (f"{cfg.input_file}" if real else
+                  "synthetic 100-column stand-in for data/input.h5 (cold regime), tiled + synthetic-parameters")
+    else:
+        nz = 137
+        nx = cfg.num_cols or 100
+        grid = ComputationalGrid(GridConfig(nx=nx, ny=1, nz=nz))
+        rank, world = _rank_world()
+        s = synthetic.make_state(nx * world, nz, col0=rank * nx, ncols=nx, dtype=gcfg.dtypes.float, device=device)
+        state = {}
+        for name, t in s.items():
+            kdim = K - 1 / 2 if name == "f_aph" else K
+            state[name] = DataArray(storage.logical_view(t), (I, J, kdim), "")
+        dt = timedelta(seconds=3600.0)
+        groups = _groups_from_defaults()
+        source = "synthetic columns (seed 20240807) + synthetic-parameters"
+    state["time"] = datetime(1970, 1, 1)
+    # eta from GLOBAL column 0: identical on every rank by construction of the synthetic state
+    if use_file or _rank_world()[1] == 1:
+        eta_levels = EtaLevels(grid, enable_checks=cfg.sympl_enable_checks, gt4py_config=gcfg)
+        state.update(eta_levels(state))
+    else:
+        eta = torch.as_tensor(synthetic.eta_levels(nz, dtype=gcfg.dtypes.float), device=device)
+        state["f_eta"] = DataArray(eta, (K,), "")
+    print(f"[cloudsc2-hip] input: {source}; {nx} columns x {nz} levels, {cfg.precision}, backend {gcfg.backend}")
+    return dict(config=cfg, io_config=io, grid=grid, state=state, dt=dt, params=groups, nx=nx, nz=nz, source=source)
+
+
+def _rank_world() -> Tuple[int, int]:
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def init_distributed_from_env() -> None:
+    """One process per GPU under torch.distributed.run (RCCL); no-op for a single process."""
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and not dist.is_initialized():
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))

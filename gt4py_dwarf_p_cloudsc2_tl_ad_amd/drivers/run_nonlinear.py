@@ -1,0 +1,84 @@
+"""NL driver: counterpart of /root/reference/drivers/run_nonlinear.py:51-232."""
+from __future__ import annotations
+
+import argparse
+import os
+
+from ..framework.iox import HDF5GridOperator
+from ..framework.output import print_performance, write_performance_to_csv, write_stencils_performance_to_csv
+from ..framework.timing import timing
+from ..framework.validation import validate
+from ..physics import Cloudsc2NL, Saturation
+from ._common import DATA_DIR, add_common_options, init_distributed_from_env, setup
+
+
+def core(args):
+    ctx = setup(args)
+    cfg, grid, state, dt, p = ctx["config"], ctx["grid"], ctx["state"], ctx["dt"], ctx["params"]
+    kw = dict(enable_checks=cfg.sympl_enable_checks, gt4py_config=cfg.gt4py_config)
+    saturation = Saturation(grid, kflag=1, lphylin=True, yoethf_params=p["yoethf"], yomcst_params=p["yomcst"], **kw)
+    diags = saturation(state)
+    state.update(diags)
+    cloudsc2_nl = Cloudsc2NL(grid, lphylin=True, ldrain1d=False, yoethf_params=p["yoethf"],
+                             yomcst_params=p["yomcst"], yrecldp_params=p["yrecldp"], yrephli_params=p["yrephli"],
+                             yrphnc_params=p["yrphnc"], **kw)
+    tends, diags_cloudsc = cloudsc2_nl(state, dt)          # warm-up + allocation (run_nonlinear.py:109)
+    diags.update(diags_cloudsc)
+    cfg.gt4py_config.reset_exec_info()
+    runtimes = []
+    for i in range(cfg.num_runs):
+        with timing(f"run_{i}") as timer:
+            saturation(state, out=diags)
+            cloudsc2_nl(state, dt, out_tendencies=tends, out_diagnostics=diags)
+        runtimes.append(timer.get_time(f"run_{i}", units="ms"))
+    mean, std, mf_mean, mf_std = print_performance(ctx["nx"], runtimes)
+    io = ctx["io_config"]
+    if io.output_csv_file is not None:
+        write_performance_to_csv(io.output_csv_file, io.host_name, cfg.precision, "nl-" + cfg.gt4py_config.backend,
+                                 ctx["nx"], cfg.num_threads, 1, cfg.num_runs, mean, std, mf_mean, mf_std)
+    if cfg.enable_validation:
+        ref_file = os.path.join(DATA_DIR, f"reference_{cfg.precision}.h5")
+        print("\n== Validation:")
+        if ctx["source"].startswith("synthetic"):
+            print("  inputs are synthetic: the golden file's inputs (data/input.h5) are not available, so a "
+                  "mismatch below says nothing about the kernels (see tests/ for the parity evidence)")
+        try:
+            gop = HDF5GridOperator(ref_file, ctx["grid"], gt4py_config=cfg.gt4py_config)
+        except FileNotFoundError:
+            print(f"  reference file {ref_file} not found - skipped")
+            return ctx
+        from ..framework.grid import D5, IJ, ExpandedDim, I, J, K
+        ref_t = {"f_qi": ("TENDENCY_LOC_CLD", 1), "f_ql": ("TENDENCY_LOC_CLD", 0), "f_qv": ("TENDENCY_LOC_Q", None),
+                 "f_t": ("TENDENCY_LOC_T", None)}
+        ref_d = {"f_clc": ("PCLC", False), "f_covptot": ("PCOVPTOT", False), "f_fhpsl": ("PFHPSL", True),
+                 "f_fhpsn": ("PFHPSN", True), "f_fplsl": ("PFPLSL", True), "f_fplsn": ("PFPLSN", True)}
+        tends_ref = {}
+        for n, (h5, idx) in ref_t.items():
+            dims_map = (IJ, ExpandedDim, K) if idx is None else (IJ, ExpandedDim, K, D5[idx])
+            tends_ref[n] = gop.get_field((I, J, K), "float", "", h5, (K, IJ) if idx is None else (D5, K, IJ), dims_map)
+        diags_ref = {}
+        for n, (h5, half) in ref_d.items():
+            kd = K - 1 / 2 if half else K
+            diags_ref[n] = gop.get_field((I, J, kd), "float", "", h5, (kd, IJ), (IJ, ExpandedDim, kd))
+        validate(tends, tends_ref, atol=cfg.atol, rtol=cfg.rtol)
+        validate(diags, diags_ref, atol=cfg.atol, rtol=cfg.rtol)
+    if args.output_csv_file_stencils is not None:
+        write_stencils_performance_to_csv(args.output_csv_file_stencils, io.host_name, cfg.precision,
+                                          "nl-" + cfg.gt4py_config.backend, ctx["nx"], cfg.num_threads, cfg.num_runs,
+                                          cfg.gt4py_config.exec_info, key_patterns=["cloudsc", "saturation"])
+    ctx.update(tends=tends, diags=diags, runtimes_ms=runtimes)
+    return ctx
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__)
+    add_common_options(ap)
+    ap.add_argument("--atol", type=float, default=None)
+    ap.add_argument("--rtol", type=float, default=None)
+    args = ap.parse_args(argv)
+    init_distributed_from_env()
+    return core(args)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,43 @@
+"""AD symmetry-test driver: counterpart of /root/reference/drivers/run_symmetry_test.py:41-194."""
+from __future__ import annotations
+
+import argparse
+import statistics
+
+from ..framework.timing import timing
+from ..harness import SymmetryTest
+from ._common import add_common_options, init_distributed_from_env, setup
+
+
+def core(args):
+    ctx = setup(args)
+    cfg, p = ctx["config"], ctx["params"]
+    st = SymmetryTest(ctx["grid"], factor=0.01, kflag=1, lphylin=True, ldrain1d=False, yoethf_params=p["yoethf"],
+                      yomcst_params=p["yomcst"], yrecldp_params=p["yrecldp"], yrephli_params=p["yrephli"],
+                      yrncl_params=p["yrncl"], yrphnc_params=p["yrphnc"], enable_checks=cfg.sympl_enable_checks,
+                      gt4py_config=cfg.gt4py_config, ad_traj_fix=args.ad_traj_fix)
+    ok = st(ctx["state"], ctx["dt"], enable_validation=cfg.enable_validation)   # warm-up + the validated call
+    runtimes = []
+    for i in range(cfg.num_runs):
+        with timing(f"run_{i}") as timer:
+            st(ctx["state"], ctx["dt"], enable_validation=False)
+        runtimes.append(timer.get_time(f"run_{i}", units="ms"))
+    mean = statistics.fmean(runtimes)
+    std = statistics.stdev(runtimes) if len(runtimes) > 1 else 0.0
+    print(f"\nThe test completed in {mean:.3f} ± {std:.3f} ms.")
+    ctx.update(passed=ok, detail=st.last, runtimes_ms=runtimes)
+    return ctx
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__)
+    add_common_options(ap)
+    ap.add_argument("--ad-traj-fix", action="store_true",
+                    help="use the AD kernel whose freezing tests match NL/TL (build extension, DESIGN.md 3.3)")
+    args = ap.parse_args(argv)
+    init_distributed_from_env()
+    return core(args)
+
+
+if __name__ == "__main__":
+    main()

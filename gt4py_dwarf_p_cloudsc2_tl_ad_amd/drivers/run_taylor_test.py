@@ -1,0 +1,42 @@
+"""TL Taylor-test driver: counterpart of /root/reference/drivers/run_taylor_test.py:41-196."""
+from __future__ import annotations
+
+import argparse
+import statistics
+
+from ..framework.timing import Timer
+from ..harness import TaylorTest
+from ._common import add_common_options, init_distributed_from_env, setup
+
+
+def core(args):
+    ctx = setup(args)
+    cfg, p = ctx["config"], ctx["params"]
+    tt = TaylorTest(ctx["grid"], factor1=0.01, factor2s=tuple(10 ** -(i + 1) for i in range(10)), kflag=1,
+                    lphylin=True, ldrain1d=False, yoethf_params=p["yoethf"], yomcst_params=p["yomcst"],
+                    yrecldp_params=p["yrecldp"], yrephli_params=p["yrephli"], yrncl_params=p["yrncl"],
+                    yrphnc_params=p["yrphnc"], enable_checks=cfg.sympl_enable_checks, gt4py_config=cfg.gt4py_config)
+    norms = tt.run(ctx["state"], ctx["dt"])                  # warm-up; these norms are the validated ones
+    runtimes = []
+    for _ in range(cfg.num_runs):
+        Timer.reset()
+        tt.run(ctx["state"], ctx["dt"])
+        runtimes.append(Timer.get_time("run"))
+    ok = tt.validate(norms) if cfg.enable_validation else None
+    mean = statistics.fmean(runtimes)
+    std = statistics.stdev(runtimes) if len(runtimes) > 1 else 0.0
+    print(f"\nThe test completed in {mean:.3f} ± {std:.3f} ms.")
+    ctx.update(norms=norms, passed=ok, runtimes_ms=runtimes)
+    return ctx
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__)
+    add_common_options(ap)
+    args = ap.parse_args(argv)
+    init_distributed_from_env()
+    return core(args)
+
+
+if __name__ == "__main__":
+    main()

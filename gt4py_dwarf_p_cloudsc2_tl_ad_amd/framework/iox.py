@@ -39,7 +39,8 @@ def _notice(msg: str) -> None:
 
 def synthetic_dataset(nz: int = 137, klon: int = SYNTHETIC_KLON) -> Dict[str, np.ndarray]:
     """A dict with the dataset names and layouts `get_state` expects ((K, IJ) / (D5, K, IJ), setup.py:28-43)."""
-    s = make_state(klon, nz, dtype=np.float64)
+    # stand-in for the reference's 100-column sample: same regime as its golden outputs (cold, snow only)
+    s = make_state(klon, nz, dtype=np.float64, regime="cold")
     ext = default_externals()
     d: Dict[str, np.ndarray] = {"KLEV": np.array([nz]), "KLON": np.array([klon]),
                                 "PTSPHY": np.array([DEFAULT_TIMESTEP_S])}

@@ -1,0 +1,227 @@
+"""Validation harnesses of the TL and AD schemes, on the device.
+
+Counterparts of `TaylorTest` (/root/reference/src/cloudsc2_gt4py/physics/tangent_linear/validation.py:46-261)
+and `SymmetryTest` (/root/reference/src/cloudsc2_gt4py/physics/adjoint/validation.py:44-231): same
+constructor arguments, same sequence of component calls, same norms, same verdict strings (the
+observable contract).  Differences, all on the measurement side:
+  * every reduction runs on the GPU (the reference copies ~40 fields to the host per call);
+  * with `torch.distributed` initialised the Taylor sums are all-reduced (SUM) and the symmetry
+    maximum all-reduced (MAX) over the column shards - the only communication of the whole path;
+  * `SymmetryTest(..., ad_traj_fix=True)` selects the AD kernel variant whose freezing tests match
+    NL/TL (include/cloudsc2_hip.h, `AD_TRAJ_FIX`); default False = the reference's literal behaviour.
+"""
+from __future__ import annotations
+
+import sys
+from datetime import timedelta
+from typing import Any, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import storage
+from .framework.timing import timing
+from .physics import Cloudsc2AD, Cloudsc2NL, Cloudsc2TL, PerturbedState, Saturation, StateIncrement
+
+_TENDS = ("f_t", "f_q", "f_ql", "f_qi")
+_DIAGS = ("f_clc", "f_fhpsl", "f_fhpsn", "f_fplsl", "f_fplsn", "f_covptot")
+
+
+def _sum64(x: torch.Tensor) -> torch.Tensor:
+    return x.as_subclass(torch.Tensor).sum(dtype=torch.float64)
+
+
+def _allreduce(t: torch.Tensor, op: str) -> torch.Tensor:
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM if op == "sum" else dist.ReduceOp.MAX)
+    return t
+
+
+def taylor_verdict(norms: Sequence[float]) -> Tuple[bool, str]:
+    """Scoring rule of TaylorTest.validate (tangent_linear/validation.py:183-217)."""
+    e = np.abs(1.0 - np.asarray(norms, dtype=np.float64))
+    start = next((i for i in range(e.size) if e[i] < 0.5), -1)
+    if start == -1 or start > 3:
+        return False, "The test failed with error 13."
+    test, negat = -10, 1
+    for i in range(start, e.size - 1):
+        tmp = int(e[i + 1] < e[i])
+        if negat > tmp:
+            test += 10
+        negat = tmp
+    if test == -10:
+        test = 11
+    if e[start:].min() > 1e-5:
+        test += 7
+    if e[start:].min() > 1e-6:
+        test += 5
+    if test > 5:
+        return False, f"The test failed with error {test}."
+    return True, f"The test passed with penalty {test}. HOORAY!"
+
+
+class TaylorTest:
+    def __init__(self, computational_grid, factor1: float, factor2s: Tuple[float, ...], kflag: int, lphylin: bool,
+                 ldrain1d: bool, yoethf_params, yomcst_params, yrecldp_params, yrephli_params, yrncl_params,
+                 yrphnc_params, *, enable_checks: bool = True, gt4py_config) -> None:
+        self.f1, self.f2s = factor1, tuple(factor2s)
+        # no regularization in the Taylor test (validation.py:84-85)
+        yrncl = dict(yrncl_params.dict() if hasattr(yrncl_params, "dict") else yrncl_params)
+        yrncl["LREGCL"] = False
+        kw = dict(enable_checks=enable_checks, gt4py_config=gt4py_config)
+        self.saturation = Saturation(computational_grid, kflag, lphylin, yoethf_params, yomcst_params, **kw)
+        self.cloudsc2_nl = Cloudsc2NL(computational_grid, lphylin, ldrain1d, yoethf_params, yomcst_params,
+                                      yrecldp_params, yrephli_params, yrphnc_params, **kw)
+        self.cloudsc2_tl = Cloudsc2TL(computational_grid, lphylin, ldrain1d, yoethf_params, yomcst_params,
+                                      yrecldp_params, yrephli_params, yrncl, yrphnc_params, **kw)
+        self.state_increment = StateIncrement(computational_grid, factor1, **kw)
+        self.perturbed_states = [PerturbedState(computational_grid, f2, **kw) for f2 in self.f2s]
+        self.diags_sat: Dict[str, Any] = {}
+        self.state_i: Dict[str, Any] = {}
+        self.state_p: Dict[str, Any] = {}
+        self.tends_nl: Dict[str, Any] = {}
+        self.diags_nl: Dict[str, Any] = {}
+        self.tends_tl: Dict[str, Any] = {}
+        self.diags_tl: Dict[str, Any] = {}
+        self.tends_nl_p: Dict[str, Any] = {}
+        self.diags_nl_p: Dict[str, Any] = {}
+
+    def __call__(self, state, timestep: timedelta) -> bool:
+        return self.validate(self.run(state, timestep))
+
+    def run(self, state, timestep: timedelta) -> np.ndarray:
+        """validation.py:150-181: saturation, NL, increment, TL, then 10 x (perturb, NL, norm)."""
+        with timing("run"):
+            self.diags_sat = self.saturation(state, out=self.diags_sat)
+            state.update(self.diags_sat)
+            self.tends_nl, self.diags_nl = self.cloudsc2_nl(state, timestep, out_tendencies=self.tends_nl,
+                                                            out_diagnostics=self.diags_nl)
+            self.state_i = self.state_increment(state, out=self.state_i)
+            state.update(self.state_i)
+            self.tends_tl, self.diags_tl = self.cloudsc2_tl(state, timestep, out_tendencies=self.tends_tl,
+                                                            out_diagnostics=self.diags_tl)
+        # denominators: sum of each TL perturbation field (one small device vector)
+        names = [("tends", n) for n in _TENDS] + [("diags", n) for n in _DIAGS]
+        sums_tl = torch.stack([_sum64(getattr(self, k + "_tl")[n + "_i"].data) for k, n in names])
+        sums_tl = _allreduce(sums_tl, "sum")
+        norms = np.zeros(len(self.f2s))
+        for i, perturbed_state in enumerate(self.perturbed_states):
+            with timing("run"):
+                self.state_p = perturbed_state(state, out=self.state_p)
+                self.state_p["time"] = state.get("time")
+                self.state_p["f_eta"] = state["f_eta"]
+                self.tends_nl_p, self.diags_nl_p = self.cloudsc2_nl(
+                    self.state_p, timestep, out_tendencies=self.tends_nl_p, out_diagnostics=self.diags_nl_p)
+            with timing("norms"):
+                diffs = torch.stack([_sum64(getattr(self, k + "_nl_p")[n].data - getattr(self, k + "_nl")[n].data)
+                                     for k, n in names])
+                diffs = _allreduce(diffs, "sum")
+                norms[i] = self._norm(self.f2s[i], diffs.cpu().numpy(), sums_tl.cpu().numpy())
+        return norms
+
+    @staticmethod
+    def _norm(f2: float, diffs: np.ndarray, sums_tl: np.ndarray) -> float:
+        """get_norm / get_field_norm (validation.py:219-261)."""
+        total, count = 0.0, 0
+        for d, s in zip(diffs, sums_tl):
+            den = abs(f2 * s)
+            norm = abs(d) / den if den > sys.float_info.epsilon else 0.0
+            count += norm > 0
+            total += norm
+        return total / count if count > 0 else 0.0
+
+    def validate(self, norms: np.ndarray) -> bool:
+        print(">>> Taylor test: Start")
+        for f2, n in zip(self.f2s, norms):
+            print(f"  factor1 = {self.f1:.3e}, factor2 = {f2:.3e}, norm = {n:.10f}")
+        ok, log = taylor_verdict(norms)
+        print("<<< Taylor test: End")
+        print(log)
+        return ok
+
+
+class SymmetryTest:
+    def __init__(self, computational_grid, factor: float, kflag: int, lphylin: bool, ldrain1d: bool, yoethf_params,
+                 yomcst_params, yrecldp_params, yrephli_params, yrncl_params, yrphnc_params, *,
+                 enable_checks: bool = True, gt4py_config, ad_traj_fix: bool = False) -> None:
+        self.f = factor
+        kw = dict(enable_checks=enable_checks, gt4py_config=gt4py_config)
+        self.gt4py_config = gt4py_config
+        self.saturation = Saturation(computational_grid, kflag, lphylin, yoethf_params, yomcst_params, **kw)
+        self.cloudsc2_tl = Cloudsc2TL(computational_grid, lphylin, ldrain1d, yoethf_params, yomcst_params,
+                                      yrecldp_params, yrephli_params, yrncl_params, yrphnc_params, **kw)
+        self.cloudsc2_ad = Cloudsc2AD(computational_grid, lphylin, ldrain1d, yoethf_params, yomcst_params,
+                                      yrecldp_params, yrephli_params, yrncl_params, yrphnc_params,
+                                      ad_traj_fix=ad_traj_fix, **kw)
+        self.state_increment = StateIncrement(computational_grid, factor, ignore_supsat=True, **kw)
+        self.diags_sat: Dict[str, Any] = {}
+        self.state_i: Dict[str, Any] = {}
+        self.tends_tl: Dict[str, Any] = {}
+        self.diags_tl: Dict[str, Any] = {}
+        self.tends_ad: Dict[str, Any] = {}
+        self.diags_ad: Dict[str, Any] = {}
+        self.last: Optional[Dict[str, Any]] = None
+
+    def __call__(self, state, timestep: timedelta, enable_validation: bool = True) -> Optional[bool]:
+        """validation.py:132-165."""
+        self.diags_sat = self.saturation(state, out=self.diags_sat)
+        state.update(self.diags_sat)
+        self.state_i = self.state_increment(state, out=self.state_i)
+        state.update(self.state_i)
+        self.tends_tl, self.diags_tl = self.cloudsc2_tl(state, timestep, out_tendencies=self.tends_tl,
+                                                        out_diagnostics=self.diags_tl)
+        norm1 = self._norm1() if enable_validation else None
+        for n in _TENDS:                                        # add_tendencies_to_state (:222-231)
+            state["f_tnd_" + n[2:]] = self.tends_tl[n]
+            state["f_tnd_" + n[2:] + "_i"] = self.tends_tl[n + "_i"]
+        state.update(self.diags_tl)
+        self.tends_ad, self.diags_ad = self.cloudsc2_ad(state, timestep, out_tendencies=self.tends_ad,
+                                                        out_diagnostics=self.diags_ad)
+        if not enable_validation:
+            return None
+        norm2 = self._norm2()
+        eps = float(np.finfo(self.gt4py_config.dtypes.float).eps)
+        diff = (norm1 - norm2).abs()
+        norm3 = torch.where(norm2 == 0, diff / eps, diff / (eps * norm2))
+        worst = _allreduce(norm3.max().reshape(1), "max")
+        passed_cols = _allreduce((norm3 < 1e4).sum().to(torch.float64).reshape(1), "sum")
+        total_cols = _allreduce(torch.tensor([float(norm3.numel())], dtype=torch.float64, device=norm3.device), "sum")
+        worst = float(worst.item())
+        self.last = {"max_error_eps": worst, "columns_passing": int(passed_cols.item()),
+                     "columns": int(total_cols.item())}
+        ok = worst < 1e4
+        print("The symmetry test passed. HOORAY!" if ok else "The symmetry test failed.")
+        print(f"The maximum error is {worst:.10e} times the machine epsilon.")
+        if not ok:
+            print(f"  ({self.last['columns_passing']} of {self.last['columns']} columns pass; the others are columns "
+                  "whose saturation adjustment crosses RTT, where the reference's AD differs from its TL - "
+                  "DESIGN.md 3.3, quirks Q4/Q5)")
+        return ok
+
+    @staticmethod
+    def _cols(x: torch.Tensor) -> torch.Tensor:
+        return x.as_subclass(torch.Tensor)[:, 0, :].to(torch.float64)
+
+    def _norm1(self) -> torch.Tensor:
+        """get_norm1 (:167-181): per-column sum over levels and fields of (TL output perturbation)^2."""
+        out = None
+        for dct, names in ((self.tends_tl, _TENDS), (self.diags_tl, _DIAGS)):
+            for n in names:
+                f = self._cols(dct[n + "_i"].data)
+                out = (f * f).sum(dim=1) if out is None else out + (f * f).sum(dim=1)
+        return out
+
+    def _norm2(self) -> torch.Tensor:
+        """get_norm2 (:183-215): per-column <delta x, AD output>."""
+        out = None
+        pairs: List[Tuple[torch.Tensor, torch.Tensor]] = []
+        for n in ("t", "q", "ql", "qi"):
+            pairs.append((self.state_i["f_tnd_cml_" + n + "_i"].data, self.tends_ad["f_cml_" + n + "_i"].data))
+        for n in ("ap", "aph", "t", "q", "qsat", "ql", "qi", "lu", "lude", "mfd", "mfu", "supsat"):
+            pairs.append((self.state_i["f_" + n + "_i"].data, self.diags_ad["f_" + n + "_i"].data))
+        for a, b in pairs:
+            s = (self._cols(a) * self._cols(b)).sum(dim=1)
+            out = s if out is None else out + s
+        return out

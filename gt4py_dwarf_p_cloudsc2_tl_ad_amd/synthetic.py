@@ -158,13 +158,21 @@ def make_state(
     device: Optional[Any] = None,
     seed: int = SEED,
     externals: Optional[Mapping[str, Any]] = None,
+    regime: str = "mixed",
 ) -> Dict[str, Any]:
     """Columns [col0, col0+ncols) of the global nx-column synthetic problem.
 
     Returns ``{name: array[(nz+1), ncols]}`` for the 15 `STATE_FIELDS` (NumPy arrays when
     `device` is None, torch tensors on `device` otherwise).  `f_qsat` and `f_eta` are *not*
     produced here: they come from the saturation / eta-level operators, as in the drivers
-    (/root/reference/drivers/run_nonlinear.py:76-94)."""
+    (/root/reference/drivers/run_nonlinear.py:76-94).
+
+    `regime`: "mixed" (default) spans warm-rain, melting and all-ice columns - used by every parity
+    test; "cold" keeps the surface below freezing (243..268 K), i.e. the regime of the reference's own
+    100-column sample as its golden outputs show it (snow only: no rain, no melting - SURVEY.md F6) -
+    used as the stand-in for `data/input.h5` by the drivers."""
+    if regime not in ("mixed", "cold"):
+        raise ValueError(f"unknown regime {regime!r}")
     if ncols is None:
         ncols = nx - col0
     if col0 < 0 or ncols < 0 or col0 + ncols > nx:
@@ -205,7 +213,10 @@ def make_state(
     ap = ps * sig_f  # = 0.5 (aph[k] + aph[k+1]) on full levels, 0 on the padding level
 
     # temperature: 6.5 K/km lapse-rate troposphere over an isothermal stratosphere + noise
-    ts = 288.0 + (-25.0 + 35.0 * ucol("f_t"))
+    if regime == "cold":
+        ts = 288.0 + (-45.0 + 25.0 * ucol("f_t"))
+    else:
+        ts = 288.0 + (-25.0 + 35.0 * ucol("f_t"))
     t_trop = ts * xp.maximum(sig_f, 1e-6) ** 0.190263
     t_strat = 216.65 + 0.0 * t_trop
     tt = xp.maximum(t_trop, t_strat) + 1.5 * normal("f_t", 2)

@@ -1,0 +1,62 @@
+"""Multi-process path on the CPU (`gloo`, world_size 2): columns shard embarrassingly, the ONLY
+communication is the all-reduce of the validation scalars (harness._allreduce; RCCL on the GPUs,
+gloo here).  Two ranks with 48 columns each of a global 96-column problem must reproduce the
+single-process 96-column Taylor norms and symmetry verdict; `eta` comes from GLOBAL column 0 on every
+rank (common/diagnostics.py:42-45 reads column 0 of the whole domain)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "dist_worker.py")
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _result(stdout):
+    line = [l for l in stdout.splitlines() if l.startswith("RESULT ")][-1]
+    return json.loads(line[len("RESULT "):])
+
+
+def test_two_rank_shards_reproduce_the_single_process_result():
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    single = subprocess.run([sys.executable, WORKER, "96"], capture_output=True, text=True, timeout=900,
+                            env={**env, "WORLD_SIZE": "1", "RANK": "0"})
+    assert single.returncode == 0, single.stderr[-3000:]
+    ref = _result(single.stdout)
+    port = str(_free_port())
+    procs = []
+    for rank in range(2):
+        e = {**env, "WORLD_SIZE": "2", "RANK": str(rank), "LOCAL_RANK": str(rank), "MASTER_ADDR": "127.0.0.1",
+             "MASTER_PORT": port}
+        procs.append(subprocess.Popen([sys.executable, WORKER, "48"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                      text=True, env=e))
+    outs = [p.communicate(timeout=900) for p in procs]
+    for p, (o, err) in zip(procs, outs):
+        assert p.returncode == 0, err[-3000:]
+    got = _result(outs[0][0])
+    np.testing.assert_allclose(got["norms"][:8], ref["norms"][:8], rtol=1e-9)
+    assert got["symmetry"]["columns"] == ref["symmetry"]["columns"] == 96
+    assert got["symmetry"]["columns_passing"] == ref["symmetry"]["columns_passing"] == 96
+    assert abs(got["symmetry"]["max_error_eps"] - ref["symmetry"]["max_error_eps"]) < 1e-6
+
+
+def test_shards_are_slices_of_the_global_problem():
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.synthetic import eta_levels, make_state
+
+    whole = make_state(96)
+    for rank in range(2):
+        part = make_state(96, col0=rank * 48, ncols=48)
+        for k in whole:
+            assert np.array_equal(part[k], whole[k][:, rank * 48:(rank + 1) * 48]), k
+    s0 = make_state(96, col0=0, ncols=1)
+    eta = eta_levels()
+    assert np.array_equal(eta[:137], s0["f_ap"][:137, 0] / s0["f_aph"][137, 0])   # global column 0, any shard count

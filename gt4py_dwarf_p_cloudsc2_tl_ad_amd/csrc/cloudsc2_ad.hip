@@ -34,39 +34,40 @@ struct ADIn {
 };
 
 template <typename T>
-__device__ __forceinline__ ADIn<T> ad_load(const CPtrs<T, NL_NUM_IN>& in, int64_t ls, int col, int k) {
-    const int64_t o = int64_t(k) * ls + col;
+__device__ __forceinline__ ADIn<T> ad_load(const CPtrs<T, NL_NUM_IN>& in, uint32_t lsb, uint32_t o) {
     ADIn<T> x;
-    x.ap = in.p[NL_IN_AP][o];
-    x.aph1 = in.p[NL_IN_APH][o + ls];
-    x.lu1 = in.p[NL_IN_LU][o + ls];
-    x.lude = in.p[NL_IN_LUDE][o];
-    x.mfd = in.p[NL_IN_MFD][o];
-    x.mfu = in.p[NL_IN_MFU][o];
-    x.q = in.p[NL_IN_Q][o];
-    x.qi = in.p[NL_IN_QI][o];
-    x.ql = in.p[NL_IN_QL][o];
-    x.qsat = in.p[NL_IN_QSAT][o];
-    x.supsat = in.p[NL_IN_SUPSAT][o];
-    x.t = in.p[NL_IN_T][o];
-    x.tq = in.p[NL_IN_TND_CML_Q][o];
-    x.tqi = in.p[NL_IN_TND_CML_QI][o];
-    x.tql = in.p[NL_IN_TND_CML_QL][o];
-    x.tt = in.p[NL_IN_TND_CML_T][o];
+    x.ap = ldg(in.p[NL_IN_AP], o);
+    x.aph1 = ldg(in.p[NL_IN_APH], o + lsb);
+    x.lu1 = ldg(in.p[NL_IN_LU], o + lsb);
+    x.lude = ldg(in.p[NL_IN_LUDE], o);
+    x.mfd = ldg(in.p[NL_IN_MFD], o);
+    x.mfu = ldg(in.p[NL_IN_MFU], o);
+    x.q = ldg(in.p[NL_IN_Q], o);
+    x.qi = ldg(in.p[NL_IN_QI], o);
+    x.ql = ldg(in.p[NL_IN_QL], o);
+    x.qsat = ldg(in.p[NL_IN_QSAT], o);
+    x.supsat = ldg(in.p[NL_IN_SUPSAT], o);
+    x.t = ldg(in.p[NL_IN_T], o);
+    x.tq = ldg(in.p[NL_IN_TND_CML_Q], o);
+    x.tqi = ldg(in.p[NL_IN_TND_CML_QI], o);
+    x.tql = ldg(in.p[NL_IN_TND_CML_QL], o);
+    x.tt = ldg(in.p[NL_IN_TND_CML_T], o);
     return x;
 }
 
-// Saved state of the two saturation-adjustment iterations (cuadjtqs:53-91).
+// Saved state of the two saturation-adjustment iterations (cuadjtqs:53-91), including the
+// reciprocals the reverse sweep divides by: r = 1/(targ - z4es), rden = 1/(1 + qsat cor z2s).
 template <typename T>
 struct CuadjSav {
     T z4es, z5alcp, zaldcp, dfo;  // dfo = z3es * (RTT - z4es)
-    T foeew_b, qsat_d, targ_b, qsat_b, cor_b, z2s_b, q_b;
-    T foeew_a, qsat_c, targ_a, qsat_a, cor_a, z2s_a, q_a;
+    T foeew_b, qsat_d, r_b, qsat_b, cor_b, z2s_b, q_b, rden_b;
+    T foeew_a, qsat_c, r_a, qsat_a, cor_a, z2s_a, q_a, rden_a;
     bool ltest2, ltest1;
 };
 
 template <typename T>
-__device__ __forceinline__ void cuadj_fwd_save(const Ext<T>& e, T ap, T& t, T& q, CuadjSav<T>& s) {
+__device__ __forceinline__ void cuadj_fwd_save(const Ext<T>& e, const ExpK<T>& xk, T rap, T& t, T& q,
+                                               CuadjSav<T>& s) {
     T z3es;
     if (t > e.RTT) {
         z3es = e.R3LES; s.z4es = e.R4LES; s.z5alcp = e.R5ALVCP; s.zaldcp = e.RALVDCP;
@@ -75,93 +76,96 @@ __device__ __forceinline__ void cuadj_fwd_save(const Ext<T>& e, T ap, T& t, T& q
     }
     s.dfo = z3es * (e.RTT - s.z4es);
     {
-        const T foeew = e.R2ES * rexp<T>(z3es * (t - e.RTT) / (t - s.z4es));
+        const T r = frcp<T>(t - s.z4es);
+        const T foeew = e.R2ES * fexp<T>(xk, z3es * (t - e.RTT) * r);
         s.foeew_b = foeew;
-        T qsat = foeew / ap;
+        T qsat = foeew * rap;
         s.ltest2 = qsat > e.ZQMAX;
         if (s.ltest2) qsat = e.ZQMAX;
-        const T cor = T(1.0) / (T(1.0) - e.RETV * qsat);
+        const T cor = frcp<T>(T(1.0) - e.RETV * qsat);
         s.qsat_d = qsat;
         qsat *= cor;
-        s.targ_b = t;
-        const T z2s = s.z5alcp / sq(t - s.z4es);
-        s.qsat_b = qsat; s.cor_b = cor; s.z2s_b = z2s; s.q_b = q;
-        const T cond1 = (q - qsat) / (T(1.0) + qsat * cor * z2s);
+        s.r_b = r;
+        const T z2s = s.z5alcp * r * r;
+        const T rden = frcp<T>(T(1.0) + qsat * cor * z2s);
+        s.qsat_b = qsat; s.cor_b = cor; s.z2s_b = z2s; s.q_b = q; s.rden_b = rden;
+        const T cond1 = (q - qsat) * rden;
         t += s.zaldcp * cond1;
         q -= cond1;
     }
     {
-        const T foeew = e.R2ES * rexp<T>(z3es * (t - e.RTT) / (t - s.z4es));
+        const T r = frcp<T>(t - s.z4es);
+        const T foeew = e.R2ES * fexp<T>(xk, z3es * (t - e.RTT) * r);
         s.foeew_a = foeew;
-        T qsat = foeew / ap;
+        T qsat = foeew * rap;
         s.ltest1 = qsat > e.ZQMAX;
         if (s.ltest1) qsat = e.ZQMAX;
-        const T cor = T(1.0) / (T(1.0) - e.RETV * qsat);
+        const T cor = frcp<T>(T(1.0) - e.RETV * qsat);
         s.qsat_c = qsat;
         qsat *= cor;
-        s.targ_a = t;
-        const T z2s = s.z5alcp / sq(t - s.z4es);
-        s.qsat_a = qsat; s.cor_a = cor; s.z2s_a = z2s; s.q_a = q;
-        const T cond1 = (q - qsat) / (T(1.0) + qsat * cor * z2s);
+        s.r_a = r;
+        const T z2s = s.z5alcp * r * r;
+        const T rden = frcp<T>(T(1.0) + qsat * cor * z2s);
+        s.qsat_a = qsat; s.cor_a = cor; s.z2s_a = z2s; s.q_a = q; s.rden_a = rden;
+        const T cond1 = (q - qsat) * rden;
         t += s.zaldcp * cond1;
         q -= cond1;
     }
 }
 
 // Reverse of one iteration (cuadjtqs:93-124 / :126-156); returns this iteration's qp_i contribution.
+// `cor` = 1 / (1 - RETV qsat_pre) is the saved value, so RETV / (1 - RETV qsat_pre)^2 = RETV cor^2.
 template <typename T>
-__device__ __forceinline__ T cuadj_bwd_iter(const Ext<T>& e, const CuadjSav<T>& s, T ap, T& t_i, T& q_i, T qsat,
-                                            T cor, T z2s, T q_sav, T targ, T qsat_pre, bool ltest, T foeew) {
+__device__ __forceinline__ T cuadj_bwd_iter(const Ext<T>& e, const CuadjSav<T>& s, T rap, T& t_i, T& q_i, T qsat,
+                                            T cor, T z2s, T q_sav, T r, T rden, T qsat_pre, bool ltest, T foeew) {
     const T cond1_i = -q_i + s.zaldcp * t_i;
-    const T den = T(1.0) + qsat * cor * z2s;
-    q_i += cond1_i / den;
-    T qsat_i = -cond1_i / den - cond1_i * (q_sav - qsat) * cor * z2s / sq(den);
-    T cor_i = -cond1_i * (q_sav - qsat) * qsat * z2s / sq(den);
-    const T z2s_i = -cond1_i * (q_sav - qsat) * qsat * cor / sq(den);
-    T targ_i = T(-2.0) * z2s_i * s.z5alcp / cube(targ - s.z4es);
+    q_i += cond1_i * rden;
+    const T w = cond1_i * (q_sav - qsat) * rden * rden;
+    T qsat_i = -cond1_i * rden - w * cor * z2s;
+    T cor_i = -w * qsat * z2s;
+    const T z2s_i = -w * qsat * cor;
+    T targ_i = T(-2.0) * z2s_i * s.z5alcp * r * r * r;
     cor_i += qsat_i * qsat_pre;
     qsat_i *= cor;
-    qsat_i += cor_i * e.RETV / sq(T(1.0) - e.RETV * qsat_pre);
+    qsat_i += cor_i * e.RETV * cor * cor;
     if (ltest) qsat_i = T(0.0);
-    const T foeew_i = qsat_i / ap;
+    const T foeew_i = qsat_i * rap;
     const T qp_i = qsat_i * foeew;
     // R2ES * exp(z3es (targ - RTT) / (targ - z4es)) is the saved foeew (cuadjtqs:117-122)
-    targ_i += foeew_i * foeew * s.dfo / sq(targ - s.z4es);
+    targ_i += foeew_i * foeew * s.dfo * r * r;
     t_i += targ_i;
     return qp_i;
 }
 
 template <typename T>
-__device__ __forceinline__ void cuadj_bwd(const Ext<T>& e, const CuadjSav<T>& s, T ap, T& ap_i, T& t_i, T& q_i) {
-    T qp_i = cuadj_bwd_iter(e, s, ap, t_i, q_i, s.qsat_a, s.cor_a, s.z2s_a, s.q_a, s.targ_a, s.qsat_c, s.ltest1,
-                            s.foeew_a);
-    qp_i += cuadj_bwd_iter(e, s, ap, t_i, q_i, s.qsat_b, s.cor_b, s.z2s_b, s.q_b, s.targ_b, s.qsat_d, s.ltest2,
-                           s.foeew_b);
-    ap_i -= qp_i / sq(ap);
+__device__ __forceinline__ void cuadj_bwd(const Ext<T>& e, const CuadjSav<T>& s, T rap, T& ap_i, T& t_i, T& q_i) {
+    T qp_i = cuadj_bwd_iter(e, s, rap, t_i, q_i, s.qsat_a, s.cor_a, s.z2s_a, s.q_a, s.r_a, s.rden_a, s.qsat_c,
+                            s.ltest1, s.foeew_a);
+    qp_i += cuadj_bwd_iter(e, s, rap, t_i, q_i, s.qsat_b, s.cor_b, s.z2s_b, s.q_b, s.r_b, s.rden_b, s.qsat_d,
+                           s.ltest2, s.foeew_b);
+    ap_i -= qp_i * rap * rap;
 }
 
-// Local trajectory of one level (:149-458), everything the backward statements read.
+// Local trajectory of one level (:149-458): everything the backward statements read, including the
+// reciprocals they divide by (computed once in the forward part).
 template <typename T>
 struct ADTraj {
-    T t2, q2, ql, qi, dp, lfdcp, lsdcp, lvdcp, fwat, foeew, esdp1, facw, faci, fac, cor, dqsdtemp;
-    T crh2, supsat, qsat, qcrit, qt, qcd, qpd, tmp3, clc, gdp, lude, out_clc;
-    T fac1, rho, fac2, rodqsdp, ldcp, fac3, dtdzmo, dqsdz, fac4, dqc, qc3;
-    T qlwc1, qiwc1, condl1, condi1, cons, z2s, snmlt;
-    T cldl, ltmp1, ltmp2, prr, cldi, itmp11, itmp12, itmp2, prs;
+    T t2, q2, ql, qi, dp, rdp, rzz, lfdcp, lsdcp, lvdcp, fwat, sech2, foeew, esdp1, rl, ri, rap, facw, faci, fac, cor;
+    T dqsdtemp, crh2, supsat, qsat, qcrit, qt, qcd, qpd, tmp3, rden, clc, gdp, lude, rlu, exlu, out_clc;
+    T fac1, rt, rho, fac2, rodqsdp, ldcp, fac3, dtdzmo, dqsdz, fac4, dqc, qc3;
+    T qlwc1, qiwc1, condl1, condi1, cons, rcons, z2s, snmlt;
+    T rclc, cldl, ltmp1, ltmp2, prr, cldi, itmp11, itmp12, itmp2, prs;
     T rfreeze1, fwatr1, t3, qold, dq, dr2, fwatr2, condl2, condi2, rfreeze3;
     T t_post, q_post, rfln, sfln, tnd_q, tnd_t, tnd_ql, tnd_qi;
-    bool lo1, lo3, melt, cloudy, t3_cold, tpost_cold;
+    bool lo1, lo3, melt, cloudy, t3_cold, tpost_cold, t2_cold;
     int cls;  // 0 clear (qt <= qcrit), 1 overcast, 2 partial
     CuadjSav<T> adj;
 };
 
 template <typename T, bool FIX>
-__device__ __forceinline__ void ad_forward(const Ext<T>& e, const ADIn<T>& x, T aph_k, int k, T eta_k, T scalm,
-                                           const CrhCol<T>& crh, T dt, T rfl, T sfl, ADTraj<T>& r) {
-    const T ckcodtl = T(2.0) * e.RKCONV * dt;
-    const T ckcodti = T(5.0) * e.RKCONV * dt;
-    const T cons2 = T(1.0) / (e.RG * dt);
-    const T meltp2 = e.RTT + T(2.0);
+__device__ __forceinline__ void ad_forward(const Ext<T>& e, const NLK<T>& kc, const ExpK<T>& xk, const ADIn<T>& x,
+                                           T aph_k, int k, T eta_k, T scalm, const CrhCol<T>& crh, T dt, T rfl, T sfl,
+                                           ADTraj<T>& r) {
     // :135-137, :153-157
     T t = x.t + dt * x.tt;
     r.t2 = t;
@@ -171,28 +175,38 @@ __device__ __forceinline__ void ad_forward(const Ext<T>& e, const ADIn<T>& x, T 
     r.q2 = q;
     // :170-174
     r.dp = x.aph1 - aph_k;
+    r.rdp = frcp<T>(r.dp);
     const T zz = e.RCPD + e.RCPD * e.RVTMP2 * q;
-    r.lfdcp = e.RLMLT / zz;
-    r.lsdcp = e.RLSTT / zz;
-    r.lvdcp = e.RLVTT / zz;
-    // :181-197
-    T z3es, z4es;
-    if (t < e.RTT) {
-        r.fwat = T(0.545) * (rtanh<T>(T(0.17) * (r.t2 - e.RLPTRC)) + T(1.0));
+    r.rzz = frcp<T>(zz);
+    r.lfdcp = e.RLMLT * r.rzz;
+    r.lsdcp = e.RLSTT * r.rzz;
+    r.lvdcp = e.RLVTT * r.rzz;
+    // :181-197;  with ex = exp(-0.34 (t2 - RLPTRC)), rr = 1/(1+ex): 0.545 (tanh u + 1) = 1.09 rr and
+    // 1/cosh(u)^2 = 4 ex rr^2 (needed by the adjoint, :967)
+    r.rl = frcp<T>(r.t2 - e.R4LES);
+    r.ri = frcp<T>(r.t2 - e.R4IES);
+    r.rap = frcp<T>(x.ap);
+    r.t2_cold = t < e.RTT;
+    T z3es, r4;
+    if (r.t2_cold) {
+        const T ex = fexp<T>(xk, -kc.fw2 * (r.t2 - e.RLPTRC));
+        const T rr = frcp<T>(T(1.0) + ex);
+        r.fwat = T(1.09) * rr;
+        r.sech2 = T(4.0) * ex * rr * rr;
         z3es = e.R3IES;
-        z4es = e.R4IES;
+        r4 = r.ri;
     } else {
         r.fwat = T(1.0);
+        r.sech2 = T(0.0);
         z3es = e.R3LES;
-        z4es = e.R4LES;
+        r4 = r.rl;
     }
-    r.foeew = e.R2ES * rexp<T>(z3es * (r.t2 - e.RTT) / (r.t2 - z4es));
-    r.esdp1 = r.foeew / x.ap;
-    const T esdp = rmin<T>(r.esdp1, e.ZQMAX);
-    r.facw = e.R5LES / sq(r.t2 - e.R4LES);
-    r.faci = e.R5IES / sq(r.t2 - e.R4IES);
+    r.foeew = e.R2ES * fexp<T>(xk, z3es * (r.t2 - e.RTT) * r4);
+    r.esdp1 = r.foeew * r.rap;
+    r.facw = e.R5LES * r.rl * r.rl;
+    r.faci = e.R5IES * r.ri * r.ri;
     r.fac = r.fwat * r.facw + (T(1.0) - r.fwat) * r.faci;
-    r.cor = T(1.0) / (T(1.0) - e.RETV * esdp);
+    r.cor = (r.esdp1 > e.ZQMAX) ? kc.cormax : frcp<T>(T(1.0) - e.RETV * r.esdp1);
     r.dqsdtemp = r.fac * r.cor * x.qsat;
     // :203-231
     r.crh2 = crh2_at(crh, eta_k);
@@ -202,6 +216,7 @@ __device__ __forceinline__ void ad_forward(const Ext<T>& e, const ADIn<T>& x, T 
     // :234-252
     r.qt = q + r.ql + r.qi;
     T qc1;
+    r.rden = T(0.0);
     if (r.qt <= r.qcrit) {
         r.cls = 0;
         r.clc = T(0.0);
@@ -220,32 +235,38 @@ __device__ __forceinline__ void ad_forward(const Ext<T>& e, const ADIn<T>& x, T 
         r.cls = 2;
         r.qcd = r.qsat - r.qcrit;
         r.qpd = r.qsat - r.qt;
-        r.tmp3 = rsqrt_<T>(r.qpd / (r.qcd - scalm * (r.qt - r.qcrit)));
+        r.rden = frcp<T>(r.qcd - scalm * (r.qt - r.qcrit));
+        r.tmp3 = rsqrt_<T>(r.qpd * r.rden);
         r.clc = T(1.0) - r.tmp3;
         qc1 = (scalm * r.qpd + (T(1.0) - scalm) * r.qcd) * sq(r.clc);
     }
     // :255-263
-    r.gdp = e.RG / (x.aph1 - aph_k);
+    r.gdp = e.RG * r.rdp;
     r.lude = dt * x.lude * r.gdp;
     r.lo1 = r.lude >= e.RLMIN && x.lu1 >= e.ZEPS2;
     T qc2;
     if (r.lo1) {
-        r.out_clc = r.clc + (T(1.0) - r.clc) * (T(1.0) - rexp<T>(-r.lude / x.lu1));
+        r.rlu = frcp<T>(x.lu1);
+        r.exlu = fexp<T>(xk, -r.lude * r.rlu);
+        r.out_clc = r.clc + (T(1.0) - r.clc) * (T(1.0) - r.exlu);
         qc2 = qc1 + r.lude;
     } else {
+        r.rlu = T(0.0);
+        r.exlu = T(0.0);
         r.out_clc = r.clc;
         qc2 = qc1;
     }
     // :266-277
-    r.fac1 = T(1.0) / (e.RD * r.t2);
+    r.rt = frcp<T>(r.t2);
+    r.fac1 = r.rt * kc.rRD;
     r.rho = x.ap * r.fac1;
-    r.fac2 = T(1.0) / (x.ap - e.RETV * r.foeew);
+    r.fac2 = frcp<T>(x.ap - e.RETV * r.foeew);
     r.rodqsdp = -r.rho * x.qsat * r.fac2;
     r.ldcp = r.fwat * r.lvdcp + (T(1.0) - r.fwat) * r.lsdcp;
-    r.fac3 = T(1.0) / (T(1.0) + r.ldcp * r.dqsdtemp);
-    r.dtdzmo = e.RG * (T(1.0) / e.RCPD - r.ldcp * r.rodqsdp) * r.fac3;
+    r.fac3 = frcp<T>(T(1.0) + r.ldcp * r.dqsdtemp);
+    r.dtdzmo = e.RG * (kc.rRCPD - r.ldcp * r.rodqsdp) * r.fac3;
     r.dqsdz = r.dqsdtemp * r.dtdzmo - e.RG * r.rodqsdp;
-    r.fac4 = T(1.0) / r.rho;
+    r.fac4 = e.RD * r.t2 * r.rap;
     const T sub = dt * r.dqsdz * (x.mfu + x.mfd) * r.fac4;
     r.lo3 = sub < qc2;
     r.dqc = rmin<T>(sub, qc2);
@@ -253,20 +274,22 @@ __device__ __forceinline__ void ad_forward(const Ext<T>& e, const ADIn<T>& x, T 
     // :280-283
     r.qlwc1 = r.qc3 * r.fwat;
     r.qiwc1 = r.qc3 * (T(1.0) - r.fwat);
-    r.condl1 = (r.qlwc1 - r.ql) / dt;
-    r.condi1 = (r.qiwc1 - r.qi) / dt;
-    // :293-302 melting of incoming snow
+    r.condl1 = (r.qlwc1 - r.ql) * kc.rdt;
+    r.condi1 = (r.qiwc1 - r.qi) * kc.rdt;
+    // :293-302 melting of incoming snow;  cons = cons2 dp / lfdcp = cons2 dp zz / RLMLT
     r.melt = sfl != T(0.0);
     T rfln, sfln;
     if (r.melt) {
-        r.cons = cons2 * r.dp / r.lfdcp;
-        r.z2s = r.cons * rmax<T>(r.t2 - meltp2, T(0.0));
+        r.cons = kc.cons2 * r.dp * zz * kc.rRLMLT;
+        r.rcons = frcp<T>(r.cons);
+        r.z2s = r.cons * rmax<T>(r.t2 - kc.meltp2, T(0.0));
         r.snmlt = rmin<T>(sfl, r.z2s);
         rfln = rfl + r.snmlt;
         sfln = sfl - r.snmlt;
-        t = r.t2 - r.snmlt / r.cons;
+        t = r.t2 - r.snmlt * r.rcons;
     } else {
         r.cons = T(1.0);
+        r.rcons = T(1.0);
         r.z2s = T(0.0);
         r.snmlt = T(0.0);
         rfln = rfl;
@@ -276,41 +299,40 @@ __device__ __forceinline__ void ad_forward(const Ext<T>& e, const ADIn<T>& x, T 
     r.cloudy = r.out_clc > e.ZEPS2;
     T qlwc = r.qlwc1, qiwc = r.qiwc1;
     if (r.cloudy) {
-        const T lcrit = T(2.0) * e.RCLCRIT;
-        r.cldl = r.qlwc1 / r.out_clc;
-        r.ltmp1 = rexp<T>(-sq(r.cldl / lcrit));
-        const T dl = ckcodtl * (T(1.0) - r.ltmp1);
-        r.ltmp2 = rexp<T>(-dl);
+        r.rclc = frcp<T>(r.out_clc);
+        r.cldl = r.qlwc1 * r.rclc;
+        r.ltmp1 = fexp<T>(xk, -sq(r.cldl * kc.rlcrit));
+        const T dl = kc.ckcodtl * (T(1.0) - r.ltmp1);
+        r.ltmp2 = fexp<T>(xk, -dl);
         const T qlnew = r.out_clc * r.cldl * r.ltmp2;
         r.prr = r.qlwc1 - qlnew;
         qlwc = r.qlwc1 - r.prr;
-        const T icrit = T(2.0) * e.RCLCRIT;
-        r.cldi = r.qiwc1 / r.out_clc;
-        r.itmp11 = rexp<T>(-sq(r.cldi / icrit));
-        r.itmp12 = rexp<T>(T(0.025) * (t - e.RTT));
-        const T di = ckcodti * r.itmp12 * (T(1.0) - r.itmp11);
-        r.itmp2 = rexp<T>(-di);
+        r.cldi = r.qiwc1 * r.rclc;
+        r.itmp11 = fexp<T>(xk, -sq(r.cldi * kc.ricrit));
+        r.itmp12 = fexp<T>(xk, T(0.025) * (t - e.RTT));
+        const T di = kc.ckcodti * r.itmp12 * (T(1.0) - r.itmp11);
+        r.itmp2 = fexp<T>(xk, -di);
         const T qinew = r.out_clc * r.cldi * r.itmp2;
         r.prs = r.qiwc1 - qinew;
         qiwc = r.qiwc1 - r.prs;
     } else {
-        r.cldl = r.ltmp1 = r.ltmp2 = r.cldi = r.itmp11 = r.itmp12 = r.itmp2 = T(0.0);
+        r.rclc = r.cldl = r.ltmp1 = r.ltmp2 = r.cldi = r.itmp11 = r.itmp12 = r.itmp2 = T(0.0);
         r.prr = T(0.0);
         r.prs = T(0.0);
     }
     // :340-353
-    const T dr1 = cons2 * r.dp * (r.prr + r.prs);
+    const T dr1 = kc.cons2 * r.dp * (r.prr + r.prs);
     if (t < e.RTT) {
-        r.rfreeze1 = cons2 * r.dp * r.prr;
+        r.rfreeze1 = kc.cons2 * r.dp * r.prr;
         r.fwatr1 = T(0.0);
+        sfln += dr1;
     } else {
         r.rfreeze1 = T(0.0);
         r.fwatr1 = T(1.0);
+        rfln += dr1;
     }
-    rfln += r.fwatr1 * dr1;
-    sfln += (T(1.0) - r.fwatr1) * dr1;
     // :401-419 (evapr = evaps = 0)
-    const T hh = x.lude * (r.fwat * r.lvdcp + (T(1.0) - r.fwat) * r.lsdcp);
+    const T hh = x.lude * r.ldcp;
     const T dqdt = -(r.condl1 + r.condi1) + x.lude * r.gdp;
     const T dtdt = r.lvdcp * r.condl1 + r.lsdcp * r.condi1 - (hh - (r.lsdcp - r.lvdcp) * r.rfreeze1) * r.gdp;
     r.t3 = t + dt * dtdt;
@@ -318,33 +340,33 @@ __device__ __forceinline__ void ad_forward(const Ext<T>& e, const ADIn<T>& x, T 
     r.qold = q;
     // :422
     t = r.t3;
-    cuadj_fwd_save(e, x.ap, t, q, r.adj);
+    cuadj_fwd_save(e, xk, r.rap, t, q, r.adj);
     r.t_post = t;
     r.q_post = q;
     r.t3_cold = r.t3 < e.RTT;
     r.tpost_cold = t < e.RTT;
     // :425-439
     r.dq = rmax<T>(r.qold - q, T(0.0));
-    r.dr2 = cons2 * r.dp * r.dq;
+    r.dr2 = kc.cons2 * r.dp * r.dq;
     const bool frz2 = FIX ? r.tpost_cold : r.t3_cold;  // Q4
     T rfreeze2;
     if (frz2) {
         rfreeze2 = r.fwat * r.dr2;
         r.fwatr2 = T(0.0);
+        sfln += r.dr2;
     } else {
         rfreeze2 = T(0.0);
         r.fwatr2 = T(1.0);
+        rfln += r.dr2;
     }
-    r.condl2 = r.condl1 + r.fwatr2 * r.dq / dt;
-    r.condi2 = r.condi1 + (T(1.0) - r.fwatr2) * r.dq / dt;
-    rfln += r.fwatr2 * r.dr2;
-    sfln += (T(1.0) - r.fwatr2) * r.dr2;
+    r.condl2 = r.condl1 + r.fwatr2 * r.dq * kc.rdt;
+    r.condi2 = r.condi1 + (T(1.0) - r.fwatr2) * r.dq * kc.rdt;
     r.rfreeze3 = r.rfreeze1 + rfreeze2;
     // :442-455
     r.tnd_q = -(r.condl2 + r.condi2) + x.lude * r.gdp;
     r.tnd_t = r.lvdcp * r.condl2 + r.lsdcp * r.condi2 - (hh - (r.lsdcp - r.lvdcp) * r.rfreeze3) * r.gdp;
-    r.tnd_ql = (qlwc - r.ql) / dt;
-    r.tnd_qi = (qiwc - r.qi) / dt;
+    r.tnd_ql = (qlwc - r.ql) * kc.rdt;
+    r.tnd_qi = (qiwc - r.qi) * kc.rdt;
     r.rfln = rfln;
     r.sfln = sfln;
 }
@@ -357,17 +379,16 @@ struct ADForce {
 };
 
 template <typename T>
-__device__ __forceinline__ ADForce<T> ad_load_force(const CPtrs<T, NL_NUM_OUT>& a, const Ext<T>& e, int64_t ls,
-                                                    int col, int k) {
-    const int64_t o = int64_t(k) * ls + col;
+__device__ __forceinline__ ADForce<T> ad_load_force(const CPtrs<T, NL_NUM_OUT>& a, const Ext<T>& e, uint32_t lsb,
+                                                    uint32_t o) {
     ADForce<T> f;
-    f.clc = a.p[NL_OUT_CLC][o];
-    f.tnd_q = a.p[NL_OUT_TND_Q][o];
-    f.tnd_qi = a.p[NL_OUT_TND_QI][o];
-    f.tnd_ql = a.p[NL_OUT_TND_QL][o];
-    f.tnd_t = a.p[NL_OUT_TND_T][o];
-    f.fplsl1 = a.p[NL_OUT_FPLSL][o + ls] - a.p[NL_OUT_FHPSL][o + ls] * e.RLVTT;
-    f.fplsn1 = a.p[NL_OUT_FPLSN][o + ls] - a.p[NL_OUT_FHPSN][o + ls] * e.RLSTT;
+    f.clc = ldg(a.p[NL_OUT_CLC], o);
+    f.tnd_q = ldg(a.p[NL_OUT_TND_Q], o);
+    f.tnd_qi = ldg(a.p[NL_OUT_TND_QI], o);
+    f.tnd_ql = ldg(a.p[NL_OUT_TND_QL], o);
+    f.tnd_t = ldg(a.p[NL_OUT_TND_T], o);
+    f.fplsl1 = ldg(a.p[NL_OUT_FPLSL], o + lsb) - ldg(a.p[NL_OUT_FHPSL], o + lsb) * e.RLVTT;
+    f.fplsn1 = ldg(a.p[NL_OUT_FPLSN], o + lsb) - ldg(a.p[NL_OUT_FHPSN], o + lsb) * e.RLSTT;
     return f;
 }
 
@@ -381,29 +402,27 @@ struct ADOut {
     T ap, t, q, ql, qi, qsat, lude, mfd, mfu, aph1, lu1;
 };
 
-// Backward statements of one level (:494-967 + this level's share of :970-996).
+// Backward statements of one level (:494-967 + this level's share of :970-996).  Divisions use the
+// reciprocals saved with the trajectory.
 template <typename T, bool REG, bool FIX>
-__device__ __forceinline__ ADOut<T> ad_backward(const Ext<T>& e, const ADIn<T>& x, T aph_k, int k, T scalm, T dt,
-                                                T sfl, const ADTraj<T>& r, const ADForce<T>& f, ADBack<T>& b) {
+__device__ __forceinline__ ADOut<T> ad_backward(const Ext<T>& e, const NLK<T>& kc, const ADIn<T>& x, int k, T scalm,
+                                                T dt, T sfl, const ADTraj<T>& r, const ADForce<T>& f, ADBack<T>& b) {
     ADOut<T> o;
-    const T ckcodtl = T(2.0) * e.RKCONV * dt;
-    const T ckcodti = T(5.0) * e.RKCONV * dt;
-    const T ckcodtla = ckcodtl / T(100.0);
-    const T ckcodtia = ckcodti / T(100.0);
-    const T cons2 = T(1.0) / (e.RG * dt);
-    const T meltp2 = e.RTT + T(2.0);
+    const T ckcodtla = kc.ckcodtl * T(0.01);
+    const T ckcodtia = kc.ckcodti * T(0.01);
+    const T cons2 = kc.cons2, rdt = kc.rdt;
     const T lvdcp = r.lvdcp, lsdcp = r.lsdcp, fwat = r.fwat, gdp = r.gdp;
     // :500-501
     T tmp_rfln_i = b.tmp_rfln_i + b.rfl_i + f.fplsl1;
     T tmp_sfln_i = b.tmp_sfln_i + b.sfl_i + f.fplsn1;
     // :504-511
-    T o_qi = -f.tnd_qi / dt;
-    T qiwc_i = f.tnd_qi / dt;
-    T o_ql = -f.tnd_ql / dt;
-    T qlwc_i = f.tnd_ql / dt;
+    T o_qi = -f.tnd_qi * rdt;
+    T qiwc_i = f.tnd_qi * rdt;
+    T o_ql = -f.tnd_ql * rdt;
+    T qlwc_i = f.tnd_ql * rdt;
     // :514-533 (evapr = evaps = 0)
     const T tt = f.tnd_t;
-    const T mix = fwat * lvdcp + (T(1.0) - fwat) * lsdcp;
+    const T mix = r.ldcp;  // fwat * lvdcp + (1 - fwat) * lsdcp
     const T hh = x.lude * mix;
     T gdp_i = -tt * (hh - (lsdcp - lvdcp) * r.rfreeze3);
     T condl_i = tt * lvdcp;
@@ -424,7 +443,7 @@ __device__ __forceinline__ ADOut<T> ad_backward(const Ext<T>& e, const ADIn<T>& 
     condl_i -= tq;
     condi_i -= tq;
     // :566-592
-    T dq_i = (r.fwatr2 * condl_i + (T(1.0) - r.fwatr2) * condi_i) / dt;
+    T dq_i = (r.fwatr2 * condl_i + (T(1.0) - r.fwatr2) * condi_i) * rdt;
     T dr2_i = r.fwatr2 * tmp_rfln_i + (T(1.0) - r.fwatr2) * tmp_sfln_i;
     if (FIX ? r.tpost_cold : r.t3_cold) {  // :577
         fwat_i += r.dr2 * rfreeze_i;
@@ -443,7 +462,7 @@ __device__ __forceinline__ ADOut<T> ad_backward(const Ext<T>& e, const ADIn<T>& 
     }
     // :594-598
     T o_ap = T(0.0), o_t = T(0.0);
-    cuadj_bwd(e, r.adj, x.ap, o_ap, o_t, o_q);
+    cuadj_bwd(e, r.adj, r.rap, o_ap, o_t, o_q);
     // :601-633
     o_q += qold_i;
     const T dqdt_i = dt * o_q;
@@ -482,35 +501,33 @@ __device__ __forceinline__ ADOut<T> ad_backward(const Ext<T>& e, const ADIn<T>& 
     // :738-782
     T a_clc = f.clc;
     if (r.cloudy) {
-        const T icrit = T(2.0) * e.RCLCRIT;
         prs_i -= qiwc_i;
         qiwc_i += prs_i;
         const T qinew_i = -prs_i;
         a_clc += qinew_i * r.cldi * r.itmp2;
         T cldi_i = qinew_i * r.out_clc * r.itmp2;
         const T di_i = -qinew_i * r.out_clc * r.cldi * r.itmp2;
-        const T itmp4 = REG ? ckcodtia : ckcodti;
+        const T itmp4 = REG ? ckcodtia : kc.ckcodti;
         o_t += T(0.025) * itmp4 * r.itmp12 * (T(1.0) - r.itmp11) * di_i;
-        cldi_i += T(2.0) * itmp4 * r.itmp12 * r.itmp11 * r.cldi * di_i / sq(icrit);
-        qiwc_i += cldi_i / r.out_clc;
-        a_clc -= r.qiwc1 * cldi_i / sq(r.out_clc);
-        const T lcrit = T(2.0) * e.RCLCRIT;
+        cldi_i += T(2.0) * itmp4 * r.itmp12 * r.itmp11 * r.cldi * di_i * kc.ricrit * kc.ricrit;
+        qiwc_i += cldi_i * r.rclc;
+        a_clc -= r.qiwc1 * cldi_i * r.rclc * r.rclc;
         prr_i -= qlwc_i;
         qlwc_i += prr_i;
         const T qlnew_i = -prr_i;
         a_clc += qlnew_i * r.cldl * r.ltmp2;
         T cldl_i = qlnew_i * r.out_clc * r.ltmp2;
         const T dl_i = -qlnew_i * r.out_clc * r.cldl * r.ltmp2;
-        const T ltmp4 = REG ? ckcodtla : ckcodtl;
-        cldl_i += T(2.0) * ltmp4 * r.ltmp1 * r.cldl * dl_i / sq(lcrit);
-        qlwc_i += cldl_i / r.out_clc;
-        a_clc -= r.qlwc1 * cldl_i / sq(r.out_clc);
+        const T ltmp4 = REG ? ckcodtla : kc.ckcodtl;
+        cldl_i += T(2.0) * ltmp4 * r.ltmp1 * r.cldl * dl_i * kc.rlcrit * kc.rlcrit;
+        qlwc_i += cldl_i * r.rclc;
+        a_clc -= r.qlwc1 * cldl_i * r.rclc * r.rclc;
     }
-    // :785-806 melting of incoming snow
+    // :785-806 melting of incoming snow;  1/lfdcp = 1/(RLMLT rzz)
     T lfdcp_i;
     if (r.melt) {
-        const T snmlt_i = -o_t / r.cons + tmp_rfln_i - tmp_sfln_i;
-        T cons_i = o_t * r.snmlt / sq(r.cons);
+        const T snmlt_i = -o_t * r.rcons + tmp_rfln_i - tmp_sfln_i;
+        T cons_i = o_t * r.snmlt * r.rcons * r.rcons;
         b.rfl_i = tmp_rfln_i;
         tmp_rfln_i = T(0.0);
         b.sfl_i = tmp_sfln_i;
@@ -522,12 +539,13 @@ __device__ __forceinline__ ADOut<T> ad_backward(const Ext<T>& e, const ADIn<T>& 
         } else {
             z2s_i = snmlt_i;
         }
-        if (r.t2 > meltp2) {
+        if (r.t2 > kc.meltp2) {
             o_t += r.cons * z2s_i;
-            cons_i += (r.t2 - meltp2) * z2s_i;
+            cons_i += (r.t2 - kc.meltp2) * z2s_i;
         }
-        dp_i += cons2 * cons_i / r.lfdcp;
-        lfdcp_i = -cons2 * r.dp * cons_i / sq(r.lfdcp);
+        const T ilf = kc.rRLMLT * (e.RCPD + e.RCPD * e.RVTMP2 * r.q2);  // 1 / lfdcp
+        dp_i += cons2 * cons_i * ilf;
+        lfdcp_i = -cons2 * r.dp * cons_i * ilf * ilf;
     } else {
         lfdcp_i = T(0.0);
         b.rfl_i = T(0.0);  // Q8
@@ -537,10 +555,10 @@ __device__ __forceinline__ ADOut<T> ad_backward(const Ext<T>& e, const ADIn<T>& 
     b.tmp_sfln_i = tmp_sfln_i;
     // :810-817: covpclr_i = covptot_i = 0 without the evaporation block -> no contribution
     // :820-825
-    qiwc_i += condi_i / dt;
-    o_qi -= condi_i / dt;
-    qlwc_i += condl_i / dt;
-    o_ql -= condl_i / dt;
+    qiwc_i += condi_i * rdt;
+    o_qi -= condi_i * rdt;
+    qlwc_i += condl_i * rdt;
+    o_ql -= condl_i * rdt;
     T qc_i = fwat * qlwc_i + (T(1.0) - fwat) * qiwc_i;
     fwat_i += r.qc3 * (qlwc_i - qiwc_i);
     // :828-842
@@ -571,21 +589,20 @@ __device__ __forceinline__ ADOut<T> ad_backward(const Ext<T>& e, const ADIn<T>& 
     o_qsat -= rodqsdp_i * r.rho * r.fac2;
     o_ap += rodqsdp_i * r.rho * x.qsat * sq(r.fac2) + rho_i * r.fac1;
     T foeew_i = -e.RETV * rodqsdp_i * r.rho * x.qsat * sq(r.fac2);
-    o_t -= rho_i * x.ap * r.fac1 / r.t2;
-    // :858-877 convective detrainment
+    o_t -= rho_i * x.ap * r.fac1 * r.rt;
+    // :858-877 convective detrainment (exp(-lude/lu1) is the saved exlu; lo1 of the forward part is the same test)
     T lude_i, dlu_i;
-    if (k < e.NLEV - 1 && r.lude >= e.RLMIN && x.lu1 >= e.ZEPS2) {
-        const T ex = rexp<T>(-r.lude / x.lu1);
-        lude_i = qc_i + (T(1.0) - r.clc) / x.lu1 * ex * a_clc;
-        dlu_i = (T(1.0) - r.clc) * r.lude / sq(x.lu1) * ex * a_clc;
-        a_clc *= T(1.0) - (T(1.0) - ex);
+    if (k < e.NLEV - 1 && r.lo1) {
+        lude_i = qc_i + (T(1.0) - r.clc) * r.rlu * r.exlu * a_clc;
+        dlu_i = (T(1.0) - r.clc) * r.lude * r.rlu * r.rlu * r.exlu * a_clc;
+        a_clc *= T(1.0) - (T(1.0) - r.exlu);
     } else {
         lude_i = T(0.0);
         dlu_i = T(0.0);
     }
     o_lude += dt * gdp * lude_i;
     gdp_i += dt * x.lude * lude_i;
-    daph_i += e.RG * gdp_i / sq(x.aph1 - aph_k);
+    daph_i += e.RG * gdp_i * r.rdp * r.rdp;
     // :880-918 Le Treut & Li cloud fraction
     T qt_i = T(0.0), qsat_i, qcrit_i;
     if (r.qt < r.qcrit) {
@@ -599,16 +616,17 @@ __device__ __forceinline__ ADOut<T> ad_backward(const Ext<T>& e, const ADIn<T>& 
         T qcd_i = (T(1.0) - scalm) * qc_i * sq(r.clc);
         a_clc += T(2.0) * (scalm * r.qpd + (T(1.0) - scalm) * r.qcd) * r.clc * qc_i;
         if constexpr (REG) {
-            const T rat = r.qpd / r.qcd;
-            const T yyy = rmin<T>(T(0.3), T(3.5) * rsqrt_<T>(rat * cube(T(1.0) - scalm * (T(1.0) - rat))) /
-                                              (T(1.0) - scalm));
+            const T rat = r.qpd * frcp<T>(r.qcd);
+            const T yyy = rmin<T>(T(0.3), T(3.5) * rsqrt_<T>(rat * cube(T(1.0) - scalm * (T(1.0) - rat))) *
+                                              frcp<T>(T(1.0) - scalm));
             a_clc *= yyy;
         }
-        const T den = r.qcd - scalm * (r.qt - r.qcrit);
-        qpd_i -= T(0.5) / r.tmp3 * a_clc / den;
-        qcd_i += T(0.5) / r.tmp3 * r.qpd * a_clc / sq(den);
-        qt_i = (T(-0.5) / r.tmp3 * (r.qpd * scalm * a_clc) / sq(den)) - qpd_i;
-        qcrit_i = (T(0.5) / r.tmp3 * (r.qpd * scalm * a_clc) / sq(den)) - qcd_i;
+        // Q10: reached with cls == 2 (tmp3 > 0, rden saved); at qt == qcrit exactly the reference divides by 0
+        const T h = T(0.5) * frcp<T>(r.tmp3) * a_clc;
+        qpd_i -= h * r.rden;
+        qcd_i += h * r.qpd * r.rden * r.rden;
+        qt_i = -h * r.qpd * scalm * r.rden * r.rden - qpd_i;
+        qcrit_i = h * r.qpd * scalm * r.rden * r.rden - qcd_i;
         qsat_i = qcd_i + qpd_i;
     }
     // :920-938
@@ -627,20 +645,16 @@ __device__ __forceinline__ ADOut<T> ad_backward(const Ext<T>& e, const ADIn<T>& 
     const T facw_i = fwat * fac_i;
     const T faci_i = (T(1.0) - fwat) * fac_i;
     fwat_i += (r.facw - r.faci) * fac_i;
-    o_t -= T(2.0) * (e.R5IES * faci_i / cube(r.t2 - e.R4IES) + e.R5LES * facw_i / cube(r.t2 - e.R4LES));
+    o_t -= T(2.0) * (e.R5IES * faci_i * cube(r.ri) + e.R5LES * facw_i * cube(r.rl));
     if (r.esdp1 > e.ZQMAX) esdp_i = T(0.0);
-    foeew_i += esdp_i / x.ap;
-    o_ap -= esdp_i * r.foeew / sq(x.ap);
-    T z3es, z4es;
-    if (r.t2 < e.RTT) {
-        z3es = e.R3IES;
-        z4es = e.R4IES;
+    foeew_i += esdp_i * r.rap;
+    o_ap -= esdp_i * r.foeew * r.rap * r.rap;
+    if (r.t2_cold) {
+        o_t += e.R3IES * (e.RTT - e.R4IES) * foeew_i * r.foeew * r.ri * r.ri;
+        o_t += T(0.545) * T(0.17) * fwat_i * r.sech2;
     } else {
-        z3es = e.R3LES;
-        z4es = e.R4LES;
+        o_t += e.R3LES * (e.RTT - e.R4LES) * foeew_i * r.foeew * r.rl * r.rl;
     }
-    o_t += z3es * (e.RTT - z4es) * foeew_i * r.foeew / sq(r.t2 - z4es);
-    if (r.t2 < e.RTT) o_t += T(0.545) * T(0.17) * fwat_i / sq(rcosh<T>(T(0.17) * (r.t2 - e.RLPTRC)));
     // :988-991
     const T zzv = e.RLVTT * lvdcp_i + e.RLSTT * lsdcp_i + e.RLMLT * lfdcp_i;
     o_q += -zzv * e.RCPD * e.RVTMP2 / sq(e.RCPD + e.RCPD * e.RVTMP2 * r.q_post);
@@ -660,14 +674,15 @@ __device__ __forceinline__ ADOut<T> ad_backward(const Ext<T>& e, const ADIn<T>& 
 }
 
 template <typename T>
-__device__ __forceinline__ T ad_trpaus(const T* __restrict__ pt, const T* __restrict__ ptt, int64_t ls, int col,
-                                       T dt, const T* s_eta, int klo, int khi) {
+__device__ __forceinline__ T ad_trpaus(const T* __restrict__ pt, const T* __restrict__ ptt, uint32_t lsb,
+                                       uint32_t colb, T dt, const T* s_eta, int klo, int khi) {
     T trpaus = T(0.1);
     if (klo <= khi) {
-        T tk = pt[int64_t(klo) * ls + col] + dt * ptt[int64_t(klo) * ls + col];
+        uint32_t o = uint32_t(klo) * lsb + colb;
+        T tk = ldg(pt, o) + dt * ldg(ptt, o);
         for (int k = klo; k <= khi; ++k) {
-            const int64_t o1 = int64_t(k + 1) * ls + col;
-            const T tk1 = pt[o1] + dt * ptt[o1];
+            o += lsb;
+            const T tk1 = ldg(pt, o) + dt * ldg(ptt, o);
             const T ek = s_eta[k];
             if (ek > T(0.1) && ek < T(0.4) && tk > tk1) trpaus = ek;
             tk = tk1;
@@ -678,50 +693,63 @@ __device__ __forceinline__ T ad_trpaus(const T* __restrict__ pt, const T* __rest
 
 template <typename T, bool REG, bool FIX>
 __global__ void __launch_bounds__(kWave)
-ad_kernel(Ext<T> e, int nx, int nz, int64_t ls, CPtrs<T, NL_NUM_IN> in, CPtrs<T, NL_NUM_OUT> adj,
-          const T* __restrict__ eta, MPtrs<T, NL_NUM_OUT> out, MPtrs<T, NL_NUM_IN> oadj, T dt) {
+ad_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, NL_NUM_IN> in,
+          CPtrs<T, NL_NUM_OUT> adj, const T* __restrict__ eta, MPtrs<T, NL_NUM_OUT> out, MPtrs<T, NL_NUM_IN> oadj,
+          T dt) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     T* s_eta = reinterpret_cast<T*>(smem_raw);
     T* s_scalm = s_eta + (nz + 1);
     int klo, khi;
     build_level_table<T>(eta, nz, e, s_eta, s_scalm, klo, khi);
+    if constexpr (sizeof(T) == 8) {
+        // fp64 constants of the level loops -> VGPRs (see pin_vgpr in cloudsc2_common.hpp)
+        pin_vgpr(e.RCPD); pin_vgpr(e.RLSTT); pin_vgpr(e.RLVTT); pin_vgpr(e.R4LES); pin_vgpr(e.R4IES);
+        pin_vgpr(e.RTT); pin_vgpr(e.R3IES); pin_vgpr(e.R3LES); pin_vgpr(e.R2ES); pin_vgpr(e.ZQMAX);
+        pin_vgpr(e.RETV); pin_vgpr(e.R5LES); pin_vgpr(e.R5IES); pin_vgpr(e.RG); pin_vgpr(e.RD);
+        pin_vgpr(kc.rdt); pin_vgpr(kc.cons2); pin_vgpr(kc.rRD); pin_vgpr(kc.rRCPD); pin_vgpr(dt);
+        pin_vgpr(xk.l2e); pin_vgpr(xk.ln2h); pin_vgpr(xk.ln2l); pin_vgpr(xk.c12); pin_vgpr(xk.c11);
+        pin_vgpr(xk.c10); pin_vgpr(xk.c9); pin_vgpr(xk.c8); pin_vgpr(xk.c7); pin_vgpr(xk.c6);
+        pin_vgpr(xk.c5); pin_vgpr(xk.c4); pin_vgpr(xk.c3);
+    }
 
     const int gcol = blockIdx.x * kWave + threadIdx.x;
     if (gcol >= nx) return;  // no later workgroup barrier: whole lanes may retire
-    const int col = gcol;
+    const uint32_t lsb = uint32_t(ls) * uint32_t(sizeof(T));
+    const uint32_t colb = uint32_t(gcol) * uint32_t(sizeof(T));
 
-    const T trpaus = ad_trpaus<T>(in.p[NL_IN_T], in.p[NL_IN_TND_CML_T], ls, col, dt, s_eta, klo, khi);
+    const T trpaus = ad_trpaus<T>(in.p[NL_IN_T], in.p[NL_IN_TND_CML_T], lsb, colb, dt, s_eta, klo, khi);
     const CrhCol<T> crh = crh_setup<T>(trpaus);
 
     // ---------------- sweep 1: trajectory + NL outputs (:146-475)
-    out.p[NL_OUT_FPLSL][col] = T(0.0);
-    out.p[NL_OUT_FPLSN][col] = T(0.0);
-    out.p[NL_OUT_FHPSL][col] = T(0.0);
-    out.p[NL_OUT_FHPSN][col] = T(0.0);
+    stg(out.p[NL_OUT_FPLSL], colb, T(0.0));
+    stg(out.p[NL_OUT_FPLSN], colb, T(0.0));
+    stg(out.p[NL_OUT_FHPSL], colb, T(0.0));
+    stg(out.p[NL_OUT_FHPSN], colb, T(0.0));
     {
         T rfl = T(0.0), sfl = T(0.0);
-        T aph_k = in.p[NL_IN_APH][col];
-        ADIn<T> xa = ad_load<T>(in, ls, col, 0);
+        T aph_k = ldg(in.p[NL_IN_APH], colb);
+        uint32_t o = colb;
+        ADIn<T> xa = ad_load<T>(in, lsb, o);
         for (int k = 0; k < nz; ++k) {
             ADIn<T> xn = xa;
-            if (k + 1 < nz) xn = ad_load<T>(in, ls, col, k + 1);
+            if (k + 1 < nz) xn = ad_load<T>(in, lsb, o + lsb);
             ADTraj<T> r;
-            ad_forward<T, FIX>(e, xa, aph_k, k, s_eta[k], s_scalm[k], crh, dt, rfl, sfl, r);
-            const int64_t i = int64_t(k) * ls + col;
-            out.p[NL_OUT_CLC][i] = r.out_clc;
-            out.p[NL_OUT_COVPTOT][i] = T(0.0);
-            out.p[NL_OUT_TND_Q][i] = r.tnd_q;
-            out.p[NL_OUT_TND_T][i] = r.tnd_t;
-            out.p[NL_OUT_TND_QL][i] = r.tnd_ql;
-            out.p[NL_OUT_TND_QI][i] = r.tnd_qi;
-            out.p[NL_OUT_FPLSL][i + ls] = r.rfln;
-            out.p[NL_OUT_FPLSN][i + ls] = r.sfln;
-            out.p[NL_OUT_FHPSL][i + ls] = -r.rfln * e.RLVTT;
-            out.p[NL_OUT_FHPSN][i + ls] = -r.sfln * e.RLSTT;
+            ad_forward<T, FIX>(e, kc, xk, xa, aph_k, k, s_eta[k], s_scalm[k], crh, dt, rfl, sfl, r);
+            stg(out.p[NL_OUT_CLC], o, r.out_clc);
+            stg(out.p[NL_OUT_COVPTOT], o, T(0.0));
+            stg(out.p[NL_OUT_TND_Q], o, r.tnd_q);
+            stg(out.p[NL_OUT_TND_T], o, r.tnd_t);
+            stg(out.p[NL_OUT_TND_QL], o, r.tnd_ql);
+            stg(out.p[NL_OUT_TND_QI], o, r.tnd_qi);
+            stg(out.p[NL_OUT_FPLSL], o + lsb, r.rfln);
+            stg(out.p[NL_OUT_FPLSN], o + lsb, r.sfln);
+            stg(out.p[NL_OUT_FHPSL], o + lsb, -r.rfln * e.RLVTT);
+            stg(out.p[NL_OUT_FHPSN], o + lsb, -r.sfln * e.RLSTT);
             rfl = r.rfln;
             sfl = r.sfln;
             aph_k = xa.aph1;
             xa = xn;
+            o += lsb;
         }
     }
 
@@ -730,52 +758,54 @@ ad_kernel(Ext<T> e, int nx, int nz, int64_t ls, CPtrs<T, NL_NUM_IN> in, CPtrs<T,
     b.tmp_rfln_i = b.tmp_sfln_i = b.rfl_i = b.sfl_i = b.daph_i = b.dp_i = T(0.0);
     {
         int k = nz - 1;
-        ADIn<T> xa = ad_load<T>(in, ls, col, k);
-        ADForce<T> fa = ad_load_force<T>(adj, e, ls, col, k);
-        T aph_k = in.p[NL_IN_APH][int64_t(k) * ls + col];
-        T sfl = out.p[NL_OUT_FPLSN][int64_t(k) * ls + col];
-        T rfl = out.p[NL_OUT_FPLSL][int64_t(k) * ls + col];
+        uint32_t o = uint32_t(k) * lsb + colb;
+        ADIn<T> xa = ad_load<T>(in, lsb, o);
+        ADForce<T> fa = ad_load_force<T>(adj, e, lsb, o);
+        T aph_k = ldg(in.p[NL_IN_APH], o);
+        T sfl = ldg(const_cast<const T*>(out.p[NL_OUT_FPLSN]), o);
+        T rfl = ldg(const_cast<const T*>(out.p[NL_OUT_FPLSL]), o);
         for (; k >= 0; --k) {
             ADIn<T> xn = xa;
             ADForce<T> fn = fa;
             T aph_n = aph_k, sfl_n = sfl, rfl_n = rfl;
             if (k > 0) {
-                xn = ad_load<T>(in, ls, col, k - 1);
-                fn = ad_load_force<T>(adj, e, ls, col, k - 1);
-                aph_n = in.p[NL_IN_APH][int64_t(k - 1) * ls + col];
-                sfl_n = out.p[NL_OUT_FPLSN][int64_t(k - 1) * ls + col];
-                rfl_n = out.p[NL_OUT_FPLSL][int64_t(k - 1) * ls + col];
+                const uint32_t om = o - lsb;
+                xn = ad_load<T>(in, lsb, om);
+                fn = ad_load_force<T>(adj, e, lsb, om);
+                aph_n = ldg(in.p[NL_IN_APH], om);
+                sfl_n = ldg(const_cast<const T*>(out.p[NL_OUT_FPLSN]), om);
+                rfl_n = ldg(const_cast<const T*>(out.p[NL_OUT_FPLSL]), om);
             }
             ADTraj<T> r;
-            ad_forward<T, FIX>(e, xa, aph_k, k, s_eta[k], s_scalm[k], crh, dt, rfl, sfl, r);
-            const ADOut<T> o = ad_backward<T, REG, FIX>(e, xa, aph_k, k, s_scalm[k], dt, sfl, r, fa, b);
-            const int64_t i = int64_t(k) * ls + col;
-            oadj.p[NL_IN_AP][i] = o.ap;
-            oadj.p[NL_IN_T][i] = o.t;
-            oadj.p[NL_IN_Q][i] = o.q;
-            oadj.p[NL_IN_QL][i] = o.ql;
-            oadj.p[NL_IN_QI][i] = o.qi;
-            oadj.p[NL_IN_QSAT][i] = o.qsat;
-            oadj.p[NL_IN_LUDE][i] = o.lude;
-            oadj.p[NL_IN_MFD][i] = o.mfd;
-            oadj.p[NL_IN_MFU][i] = o.mfu;
-            oadj.p[NL_IN_SUPSAT][i] = dt * o.q;           // :992 (Q7, literal)
-            oadj.p[NL_IN_TND_CML_T][i] = dt * o.t;        // :993-996
-            oadj.p[NL_IN_TND_CML_Q][i] = dt * o.q;
-            oadj.p[NL_IN_TND_CML_QL][i] = dt * o.ql;
-            oadj.p[NL_IN_TND_CML_QI][i] = dt * o.qi;
-            oadj.p[NL_IN_APH][i + ls] = o.aph1;
-            oadj.p[NL_IN_LU][i + ls] = o.lu1;
+            ad_forward<T, FIX>(e, kc, xk, xa, aph_k, k, s_eta[k], s_scalm[k], crh, dt, rfl, sfl, r);
+            const ADOut<T> a = ad_backward<T, REG, FIX>(e, kc, xa, k, s_scalm[k], dt, sfl, r, fa, b);
+            stg(oadj.p[NL_IN_AP], o, a.ap);
+            stg(oadj.p[NL_IN_T], o, a.t);
+            stg(oadj.p[NL_IN_Q], o, a.q);
+            stg(oadj.p[NL_IN_QL], o, a.ql);
+            stg(oadj.p[NL_IN_QI], o, a.qi);
+            stg(oadj.p[NL_IN_QSAT], o, a.qsat);
+            stg(oadj.p[NL_IN_LUDE], o, a.lude);
+            stg(oadj.p[NL_IN_MFD], o, a.mfd);
+            stg(oadj.p[NL_IN_MFU], o, a.mfu);
+            stg(oadj.p[NL_IN_SUPSAT], o, dt * a.q);           // :992 (Q7, literal)
+            stg(oadj.p[NL_IN_TND_CML_T], o, dt * a.t);        // :993-996
+            stg(oadj.p[NL_IN_TND_CML_Q], o, dt * a.q);
+            stg(oadj.p[NL_IN_TND_CML_QL], o, dt * a.ql);
+            stg(oadj.p[NL_IN_TND_CML_QI], o, dt * a.qi);
+            stg(oadj.p[NL_IN_APH], o + lsb, a.aph1);
+            stg(oadj.p[NL_IN_LU], o + lsb, a.lu1);
             xa = xn;
             fa = fn;
             aph_k = aph_n;
             sfl = sfl_n;
             rfl = rfl_n;
+            o -= lsb;
         }
     }
     // :982-986 top half level
-    oadj.p[NL_IN_APH][col] = b.daph_i - b.dp_i;
-    oadj.p[NL_IN_LU][col] = T(0.0);
+    stg(oadj.p[NL_IN_APH], colb, b.daph_i - b.dp_i);
+    stg(oadj.p[NL_IN_LU], colb, T(0.0));
 }
 
 template <typename T>
@@ -792,10 +822,13 @@ int launch_ad(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
     const dim3 grid((nx + kWave - 1) / kWave), block(kWave);
     const size_t smem = 2 * size_t(nz + 1) * sizeof(T);
     const T tdt = static_cast<T>(dt);
+    const NLK<T> kc = make_nlk<T>(p, dt, false);
+    const ExpK<T> xk = make_expk<T>();
+    if (!fits_u32_offsets<T>(nz, ls)) return -2;
     const bool reg = p.LREGCL != 0;
     const bool fix = p.AD_TRAJ_FIX != 0;
 #define CS2_AD_LAUNCH(R, F) \
-    hipLaunchKernelGGL((ad_kernel<T, R, F>), grid, block, smem, stream, e, nx, nz, ls, ci, ca, eta, co, coa, tdt)
+    hipLaunchKernelGGL((ad_kernel<T, R, F>), grid, block, smem, stream, e, kc, xk, nx, nz, ls, ci, ca, eta, co, coa, tdt)
     if (reg && !fix) CS2_AD_LAUNCH(true, false);
     else if (!reg && !fix) CS2_AD_LAUNCH(false, false);
     else if (reg && fix) CS2_AD_LAUNCH(true, true);

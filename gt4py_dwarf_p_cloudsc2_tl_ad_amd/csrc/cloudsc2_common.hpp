@@ -179,6 +179,33 @@ __device__ __forceinline__ void build_level_table(const T* __restrict__ eta, int
     }
 }
 
+// (line references in this block: nonlinear/_stencils/cloudsc2.py)
+// Level-independent derived constants (one set per launch, computed on the host in double).
+template <typename T>
+struct NLK {
+    T rdt, ckcodtl, ckcodti, cons2, rgdt, cons3, meltp2, rlcrit, ricrit, rRD, rRCPD, rRLMLT, cormax, fw2;
+};
+
+template <typename T>
+inline NLK<T> make_nlk(const Cloudsc2Params& p, double dt, bool evap) {
+    NLK<T> k;
+    k.rdt = T(1.0 / dt);
+    k.ckcodtl = T(2.0 * p.RKCONV * dt);              // :120
+    k.ckcodti = T(5.0 * p.RKCONV * dt);              // :121
+    k.cons2 = T(1.0 / (p.RG * dt));                  // :122
+    k.rgdt = T(p.RG * dt);
+    k.cons3 = T(p.RLVTT / p.RCPD);                   // :123
+    k.meltp2 = T(p.RTT + 2.0);                       // :124
+    k.rlcrit = T(1.0 / ((evap ? 1.9 : 2.0) * p.RCLCRIT));     // :250-253
+    k.ricrit = T(1.0 / (evap ? 0.0001 : 2.0 * p.RCLCRIT));    // :263-266
+    k.rRD = T(1.0 / p.RD);
+    k.rRCPD = T(1.0 / p.RCPD);
+    k.rRLMLT = T(1.0 / p.RLMLT);
+    k.cormax = T(1.0 / (1.0 - p.RETV * p.ZQMAX));    // 1 / (1 - RETV * esdp) when esdp is clipped at ZQMAX
+    k.fw2 = T(2.0 * 0.17);                           // tanh(u) + 1 = 2 / (1 + exp(-2u)), u = 0.17 (t - RLPTRC)
+    return k;
+}
+
 // Critical relative humidity profile (nonlinear/_stencils/cloudsc2.py:166-186); rh2/deta1 depend on
 // the column's tropopause eta only and are hoisted out of the level loop by the callers.
 template <typename T>

@@ -19,25 +19,24 @@ struct TLIn {
 };
 
 template <typename T>
-__device__ __forceinline__ TLIn<T> tl_load(const CPtrs<T, NL_NUM_IN>& in, int64_t ls, int col, int k) {
-    const int64_t o = int64_t(k) * ls + col;
+__device__ __forceinline__ TLIn<T> tl_load(const CPtrs<T, NL_NUM_IN>& in, uint32_t lsb, uint32_t o) {
     TLIn<T> x;
-    x.ap = in.p[NL_IN_AP][o];
-    x.aph1 = in.p[NL_IN_APH][o + ls];
-    x.lu1 = in.p[NL_IN_LU][o + ls];
-    x.lude = in.p[NL_IN_LUDE][o];
-    x.mfd = in.p[NL_IN_MFD][o];
-    x.mfu = in.p[NL_IN_MFU][o];
-    x.q = in.p[NL_IN_Q][o];
-    x.qi = in.p[NL_IN_QI][o];
-    x.ql = in.p[NL_IN_QL][o];
-    x.qsat = in.p[NL_IN_QSAT][o];
-    x.supsat = in.p[NL_IN_SUPSAT][o];
-    x.t = in.p[NL_IN_T][o];
-    x.tq = in.p[NL_IN_TND_CML_Q][o];
-    x.tqi = in.p[NL_IN_TND_CML_QI][o];
-    x.tql = in.p[NL_IN_TND_CML_QL][o];
-    x.tt = in.p[NL_IN_TND_CML_T][o];
+    x.ap = ldg(in.p[NL_IN_AP], o);
+    x.aph1 = ldg(in.p[NL_IN_APH], o + lsb);
+    x.lu1 = ldg(in.p[NL_IN_LU], o + lsb);
+    x.lude = ldg(in.p[NL_IN_LUDE], o);
+    x.mfd = ldg(in.p[NL_IN_MFD], o);
+    x.mfu = ldg(in.p[NL_IN_MFU], o);
+    x.q = ldg(in.p[NL_IN_Q], o);
+    x.qi = ldg(in.p[NL_IN_QI], o);
+    x.ql = ldg(in.p[NL_IN_QL], o);
+    x.qsat = ldg(in.p[NL_IN_QSAT], o);
+    x.supsat = ldg(in.p[NL_IN_SUPSAT], o);
+    x.t = ldg(in.p[NL_IN_T], o);
+    x.tq = ldg(in.p[NL_IN_TND_CML_Q], o);
+    x.tqi = ldg(in.p[NL_IN_TND_CML_QI], o);
+    x.tql = ldg(in.p[NL_IN_TND_CML_QL], o);
+    x.tt = ldg(in.p[NL_IN_TND_CML_T], o);
     return x;
 }
 
@@ -51,53 +50,45 @@ struct TLOut {
     T clc, clc_i, tnd_q, tnd_q_i, tnd_t, tnd_t_i, tnd_ql, tnd_ql_i, tnd_qi, tnd_qi_i, rfln, rfln_i, sfln, sfln_i;
 };
 
-// tangent_linear/_stencils/cuadjtqs.py:22-52
+// One iteration of tangent_linear/_stencils/cuadjtqs.py:22-52 with shared reciprocals
+// (rap = 1/ap from the caller, r = 1/(t - z4es) serves the exponent, foeew_i, z2s and z2s_i).
 template <typename T>
-__device__ __forceinline__ void cuadjtqs_tl_0(const Ext<T>& e, T ap, T ap_i, T& t, T& t_i, T& q, T& q_i, T z3es,
-                                              T z4es, T z5alcp, T zaldcp) {
-    const T qp = T(1.0) / ap;
-    const T qp_i = -ap_i / sq(ap);
-    const T foeew = e.R2ES * rexp<T>(z3es * (t - e.RTT) / (t - z4es));
-    const T foeew_i = foeew * z3es * t_i * (e.RTT - z4es) / sq(t - z4es);
-    T qsat = qp * foeew;
-    T qsat_i = qp_i * foeew + qp * foeew_i;
+__device__ __forceinline__ void tl_cuadj_iter(const Ext<T>& e, const ExpK<T>& xk, T rap, T ap_i, T& t, T& t_i, T& q,
+                                              T& q_i, T z3es, T z4es, T z5alcp, T zaldcp) {
+    const T qp_i = -ap_i * rap * rap;
+    const T r = frcp<T>(t - z4es);
+    const T foeew = e.R2ES * fexp<T>(xk, z3es * (t - e.RTT) * r);
+    const T foeew_i = foeew * z3es * t_i * (e.RTT - z4es) * r * r;
+    T qsat = rap * foeew;
+    T qsat_i = qp_i * foeew + rap * foeew_i;
     if (qsat > e.ZQMAX) {
         qsat = e.ZQMAX;
         qsat_i = T(0.0);
     }
-    const T cor = T(1.0) / (T(1.0) - e.RETV * qsat);
-    const T cor_i = e.RETV * qsat_i / sq(T(1.0) - e.RETV * qsat);
+    const T cor = frcp<T>(T(1.0) - e.RETV * qsat);
+    const T cor_i = e.RETV * qsat_i * cor * cor;
     qsat_i = qsat_i * cor + qsat * cor_i;
     qsat *= cor;
-    const T z2s = z5alcp / sq(t - z4es);
-    const T z2s_i = T(-2.0) * z5alcp * t_i / cube(t - z4es);
-    const T den = T(1.0) + qsat * cor * z2s;
-    const T cond = (q - qsat) / den;
-    const T cond_i = (q_i - qsat_i) / den -
-                     (q - qsat) * (qsat_i * cor * z2s + qsat * cor_i * z2s + qsat * cor * z2s_i) / sq(den);
+    const T z2s = z5alcp * r * r;
+    const T z2s_i = T(-2.0) * z5alcp * t_i * r * r * r;
+    const T rden = frcp<T>(T(1.0) + qsat * cor * z2s);
+    const T cond = (q - qsat) * rden;
+    const T cond_i = (q_i - qsat_i) * rden -
+                     (q - qsat) * (qsat_i * cor * z2s + qsat * cor_i * z2s + qsat * cor * z2s_i) * rden * rden;
     t += zaldcp * cond;
     t_i += zaldcp * cond_i;
     q -= cond;
     q_i -= cond_i;
 }
 
-// tangent_linear/_stencils/cuadjtqs.py:55-84
-template <typename T>
-__device__ __forceinline__ void cuadjtqs_tl(const Ext<T>& e, T ap, T ap_i, T& t, T& t_i, T& q, T& q_i) {
-    T z3es, z4es, z5alcp, zaldcp;
-    if (t > e.RTT) {
-        z3es = e.R3LES; z4es = e.R4LES; z5alcp = e.R5ALVCP; zaldcp = e.RALVDCP;
-    } else {
-        z3es = e.R3IES; z4es = e.R4IES; z5alcp = e.R5ALSCP; zaldcp = e.RALSDCP;
-    }
-    cuadjtqs_tl_0(e, ap, ap_i, t, t_i, q, q_i, z3es, z4es, z5alcp, zaldcp);
-    cuadjtqs_tl_0(e, ap, ap_i, t, t_i, q, q_i, z3es, z4es, z5alcp, zaldcp);
-}
-
 // One level of the forward sweep (:149-753) for one column.  x = trajectory inputs, y = perturbations.
+// Same algebra as the reference; divisions are x * frcp(y) with shared reciprocals, tanh/cosh come
+// from ONE exponential: with ex = exp(-0.34 (t - RLPTRC)), rr = 1/(1 + ex):
+//   0.545 (tanh u + 1) = 1.09 rr,   1 / cosh(u)^2 = 4 ex rr^2      (u = 0.17 (t - RLPTRC)).
 template <typename T, bool REG>
-__device__ __forceinline__ TLOut<T> tl_level(const Ext<T>& e, const TLIn<T>& x, const TLIn<T>& y, int k, T eta_k,
-                                             T scalm, const CrhCol<T>& crh, T dt, TLCarry<T>& c) {
+__device__ __forceinline__ TLOut<T> tl_level(const Ext<T>& e, const NLK<T>& kc, const ExpK<T>& xk, const TLIn<T>& x,
+                                             const TLIn<T>& y, int k, T eta_k, T scalm, const CrhCol<T>& crh, T dt,
+                                             TLCarry<T>& c) {
     TLOut<T> o;
     // :139-140, :151-156
     T t = x.t + dt * x.tt;
@@ -108,51 +99,56 @@ __device__ __forceinline__ TLOut<T> tl_level(const Ext<T>& e, const TLIn<T>& x, 
     const T ql_i = y.ql + dt * y.tql;
     const T qi = x.qi + dt * x.tqi;
     const T qi_i = y.qi + dt * y.tqi;
-    // :159-165
-    const T ckcodtl = T(2.0) * e.RKCONV * dt;
-    const T ckcodti = T(5.0) * e.RKCONV * dt;
-    const T ckcodtla = ckcodtl / T(100.0);
-    const T ckcodtia = ckcodti / T(100.0);
-    const T cons2 = T(1.0) / (e.RG * dt);
-    const T meltp2 = e.RTT + T(2.0);
     // :171-180
     const T dp = x.aph1 - c.aph_k;
     const T dp_i = y.aph1 - c.aph_k_i;
-    const T zz = T(1.0) / (e.RCPD + e.RCPD * e.RVTMP2 * q);
-    const T zz_i = -e.RCPD * e.RVTMP2 * q_i / sq(e.RCPD + e.RCPD * e.RVTMP2 * q);
+    const T rdp = frcp<T>(dp);
+    const T zden = e.RCPD + e.RCPD * e.RVTMP2 * q;
+    const T zz = frcp<T>(zden);
+    const T zz_i = -e.RCPD * e.RVTMP2 * q_i * zz * zz;
     const T lfdcp = e.RLMLT * zz, lfdcp_i = e.RLMLT * zz_i;
     const T lsdcp = e.RLSTT * zz, lsdcp_i = e.RLSTT * zz_i;
     const T lvdcp = e.RLVTT * zz, lvdcp_i = e.RLVTT * zz_i;
     // :189-205
-    T fwat, fwat_i, z3es, z4es;
+    const T rl = frcp<T>(t - e.R4LES);
+    const T ri = frcp<T>(t - e.R4IES);
+    const T rap = frcp<T>(x.ap);
+    T fwat, fwat_i, z3es, z4es, r4;
     if (t < e.RTT) {
-        fwat = T(0.545) * (rtanh<T>(T(0.17) * (t - e.RLPTRC)) + T(1.0));
-        fwat_i = T(0.545) * T(0.17) * t_i / sq(rcosh<T>(T(0.17) * (t - e.RLPTRC)));
+        const T ex = fexp<T>(xk, -kc.fw2 * (t - e.RLPTRC));
+        const T rr = frcp<T>(T(1.0) + ex);
+        fwat = T(1.09) * rr;
+        fwat_i = T(0.545) * T(0.17) * t_i * (T(4.0) * ex * rr * rr);
         z3es = e.R3IES;
         z4es = e.R4IES;
+        r4 = ri;
     } else {
         fwat = T(1.0);
         fwat_i = T(0.0);
         z3es = e.R3LES;
         z4es = e.R4LES;
+        r4 = rl;
     }
-    const T foeew = e.R2ES * rexp<T>(z3es * (t - e.RTT) / (t - z4es));
-    const T foeew_i = z3es * (e.RTT - z4es) * t_i * foeew / sq(t - z4es);
-    T esdp = foeew / x.ap;
-    T esdp_i = foeew_i / x.ap - foeew * y.ap / sq(x.ap);
+    const T foeew = e.R2ES * fexp<T>(xk, z3es * (t - e.RTT) * r4);
+    const T foeew_i = z3es * (e.RTT - z4es) * t_i * foeew * r4 * r4;
+    T esdp = foeew * rap;
+    T esdp_i = foeew_i * rap - foeew * y.ap * rap * rap;
+    T cor;
     if (esdp > e.ZQMAX) {
         esdp = e.ZQMAX;
         esdp_i = T(0.0);
+        cor = kc.cormax;
+    } else {
+        cor = frcp<T>(T(1.0) - e.RETV * esdp);
     }
     // :207-222
-    const T facw = e.R5LES / sq(t - e.R4LES);
-    const T facw_i = T(-2.0) * e.R5LES * t_i / cube(t - e.R4LES);
-    const T faci = e.R5IES / sq(t - e.R4IES);
-    const T faci_i = T(-2.0) * e.R5IES * t_i / cube(t - e.R4IES);
+    const T facw = e.R5LES * rl * rl;
+    const T facw_i = T(-2.0) * e.R5LES * t_i * rl * rl * rl;
+    const T faci = e.R5IES * ri * ri;
+    const T faci_i = T(-2.0) * e.R5IES * t_i * ri * ri * ri;
     const T fac = fwat * facw + (T(1.0) - fwat) * faci;
     const T fac_i = fwat_i * (facw - faci) + fwat * facw_i + (T(1.0) - fwat) * faci_i;
-    const T cor = T(1.0) / (T(1.0) - e.RETV * esdp);
-    const T cor_i = e.RETV * esdp_i / sq(T(1.0) - e.RETV * esdp);
+    const T cor_i = e.RETV * esdp_i * cor * cor;
     const T dqsdtemp = fac * cor * x.qsat;
     const T dqsdtemp_i = fac_i * cor * x.qsat + fac * cor_i * x.qsat + fac * cor * y.qsat;
     // (:221-230 corqs / qlim feed only the evaporation block, which is not instantiated)
@@ -191,13 +187,14 @@ __device__ __forceinline__ TLOut<T> tl_level(const Ext<T>& e, const TLIn<T>& x, 
         const T qcd = qsat - qcrit;
         const T qcd_i = qsat_i - qcrit_i;
         const T den = qcd - scalm * (qt - qcrit);
-        const T tmp1 = rsqrt_<T>(qpd / den);
+        const T rden = frcp<T>(den);
+        const T tmp1 = rsqrt_<T>(qpd * rden);
         clc = T(1.0) - tmp1;
-        clc_i = T(-0.5) / tmp1 * (qpd_i * den - qpd * (qcd_i - scalm * (qt_i - qcrit_i))) / sq(den);
+        clc_i = T(-0.5) * frcp<T>(tmp1) * (qpd_i * den - qpd * (qcd_i - scalm * (qt_i - qcrit_i))) * rden * rden;
         if constexpr (REG) {
-            const T rat = qpd / qcd;
-            const T yyy = rmin<T>(T(0.3), T(3.5) * rsqrt_<T>(rat * cube(T(1.0) - scalm * (T(1.0) - rat))) /
-                                              (T(1.0) - scalm));
+            const T rat = qpd * frcp<T>(qcd);
+            const T yyy = rmin<T>(T(0.3), T(3.5) * rsqrt_<T>(rat * cube(T(1.0) - scalm * (T(1.0) - rat))) *
+                                              frcp<T>(T(1.0) - scalm));
             clc_i *= yyy;
         }
         qc = (scalm * qpd + (T(1.0) - scalm) * qcd) * sq(clc);
@@ -205,39 +202,41 @@ __device__ __forceinline__ TLOut<T> tl_level(const Ext<T>& e, const TLIn<T>& x, 
                T(2.0) * (scalm * qpd + (T(1.0) - scalm) * qcd) * clc * clc_i;
     }
     // :309-325 convective detrainment
-    const T gdp = e.RG / (x.aph1 - c.aph_k);
-    const T gdp_i = -e.RG * (y.aph1 - c.aph_k_i) / sq(x.aph1 - c.aph_k);
+    const T gdp = e.RG * rdp;
+    const T gdp_i = -e.RG * dp_i * rdp * rdp;
     const T lude = dt * x.lude * gdp;
     const T lude_i = dt * (y.lude * gdp + x.lude * gdp_i);
     if (k < e.NLEV - 1 && lude >= e.RLMIN && x.lu1 >= e.ZEPS2) {
-        const T tmp2 = rexp<T>(-lude / x.lu1);
-        clc_i += -clc_i * (T(1.0) - tmp2) +
-                 (T(1.0) - clc) * tmp2 * (lude_i / x.lu1 - lude * y.lu1 / sq(x.lu1));
+        const T rlu = frcp<T>(x.lu1);
+        const T tmp2 = fexp<T>(xk, -lude * rlu);
+        clc_i += -clc_i * (T(1.0) - tmp2) + (T(1.0) - clc) * tmp2 * (lude_i * rlu - lude * y.lu1 * rlu * rlu);
         clc += (T(1.0) - clc) * (T(1.0) - tmp2);
         qc += lude;
         qc_i += lude_i;
     }
     // :328-354 compensating subsidence
-    const T fac1 = T(1.0) / (e.RD * t);
+    const T rt = frcp<T>(t);
+    const T fac1 = rt * kc.rRD;
     const T rho = x.ap * fac1;
-    const T rho_i = (y.ap - x.ap * t_i / t) * fac1;
-    const T fac2 = T(1.0) / (x.ap - e.RETV * foeew);
+    const T rho_i = (y.ap - x.ap * t_i * rt) * fac1;
+    const T fac2 = frcp<T>(x.ap - e.RETV * foeew);
     const T rodqsdp = -rho * x.qsat * fac2;
     const T rodqsdp_i = (-rho_i * x.qsat - rho * y.qsat + rho * x.qsat * (y.ap - e.RETV * foeew_i) * fac2) * fac2;
     const T ldcp = fwat * lvdcp + (T(1.0) - fwat) * lsdcp;
     const T ldcp_i = fwat_i * (lvdcp - lsdcp) + fwat * lvdcp_i + (T(1.0) - fwat) * lsdcp_i;
-    const T fac3 = T(1.0) / (T(1.0) + ldcp * dqsdtemp);
-    const T dtdzmo = e.RG * (T(1.0) / e.RCPD - ldcp * rodqsdp) * fac3;
+    const T fac3 = frcp<T>(T(1.0) + ldcp * dqsdtemp);
+    const T dtdzmo = e.RG * (kc.rRCPD - ldcp * rodqsdp) * fac3;
     const T dtdzmo_i = -(e.RG * (ldcp_i * rodqsdp + ldcp * rodqsdp_i) +
                          dtdzmo * (ldcp_i * dqsdtemp + ldcp * dqsdtemp_i)) * fac3;
     const T dqsdz = dqsdtemp * dtdzmo - e.RG * rodqsdp;
     const T dqsdz_i = dqsdtemp_i * dtdzmo + dqsdtemp * dtdzmo_i - e.RG * rodqsdp_i;
     // :356-373
-    const T tmp3 = dt * dqsdz * (x.mfu + x.mfd) / rho;
+    const T rrho = e.RD * t * rap;
+    const T tmp3 = dt * dqsdz * (x.mfu + x.mfd) * rrho;
     T dqc, dqc_i;
     if (tmp3 < qc) {
         dqc = tmp3;
-        dqc_i = (dt * (dqsdz_i * (x.mfu + x.mfd) + dqsdz * (y.mfu + y.mfd)) - dqc * rho_i) / rho;
+        dqc_i = (dt * (dqsdz_i * (x.mfu + x.mfd) + dqsdz * (y.mfu + y.mfd)) - dqc * rho_i) * rrho;
         if constexpr (REG) dqc_i *= T(0.1);
     } else {
         dqc = qc;
@@ -250,24 +249,25 @@ __device__ __forceinline__ TLOut<T> tl_level(const Ext<T>& e, const TLIn<T>& x, 
     T qlwc_i = qc_i * fwat + qc * fwat_i;
     T qiwc = qc * (T(1.0) - fwat);
     T qiwc_i = qc_i * (T(1.0) - fwat) - qc * fwat_i;
-    T condl = (qlwc - ql) / dt;
-    T condl_i = (qlwc_i - ql_i) / dt;
-    T condi = (qiwc - qi) / dt;
-    T condi_i = (qiwc_i - qi_i) / dt;
+    T condl = (qlwc - ql) * kc.rdt;
+    T condl_i = (qlwc_i - ql_i) * kc.rdt;
+    T condi = (qiwc - qi) * kc.rdt;
+    T condi_i = (qiwc_i - qi_i) * kc.rdt;
     // :390-397 maximum overlap (covpclr feeds only the evaporation block)
     if (clc > c.covptot) {
         c.covptot = clc;
         c.covptot_i = clc_i;
     }
-    // :400-427 melting of incoming snow
+    // :400-427 melting of incoming snow;  1/lfdcp = zden / RLMLT
     T rfln, rfln_i, sfln, sfln_i;
     if (c.sfl != T(0.0)) {
-        const T cons = cons2 * dp / lfdcp;
-        const T cons_i = cons2 * (dp_i * lfdcp - dp * lfdcp_i) / sq(lfdcp);
+        const T ilf = zden * kc.rRLMLT;
+        const T cons = kc.cons2 * dp * ilf;
+        const T cons_i = kc.cons2 * (dp_i * lfdcp - dp * lfdcp_i) * ilf * ilf;
         T z2s, z2s_i;
-        if (t > meltp2) {
-            z2s = cons * (t - meltp2);
-            z2s_i = cons_i * (t - meltp2) + cons * t_i;
+        if (t > kc.meltp2) {
+            z2s = cons * (t - kc.meltp2);
+            z2s_i = cons_i * (t - kc.meltp2) + cons * t_i;
         } else {
             z2s = T(0.0);
             z2s_i = T(0.0);
@@ -284,8 +284,9 @@ __device__ __forceinline__ TLOut<T> tl_level(const Ext<T>& e, const TLIn<T>& x, 
         rfln_i = c.rfl_i + snmlt_i;
         sfln = c.sfl - snmlt;
         sfln_i = c.sfl_i - snmlt_i;
-        t -= snmlt / cons;
-        t_i -= (snmlt_i * cons - snmlt * cons_i) / sq(cons);
+        const T rcons = frcp<T>(cons);
+        t -= snmlt * rcons;
+        t_i -= (snmlt_i * cons - snmlt * cons_i) * rcons * rcons;
     } else {
         rfln = c.rfl;
         rfln_i = c.rfl_i;
@@ -295,28 +296,27 @@ __device__ __forceinline__ TLOut<T> tl_level(const Ext<T>& e, const TLIn<T>& x, 
     // :429-503 autoconversion
     T prr = T(0.0), prr_i = T(0.0), prs = T(0.0), prs_i = T(0.0);
     if (clc > e.ZEPS2) {
-        const T lcrit = T(2.0) * e.RCLCRIT;
-        const T cldl = qlwc / clc;
-        const T cldl_i = qlwc_i / clc - qlwc * clc_i / sq(clc);
-        const T ltmp4 = rexp<T>(-sq(cldl / lcrit));
-        const T dl = ckcodtl * (T(1.0) - ltmp4);
-        const T ltmp5 = rexp<T>(-dl);
-        const T dl_i = (T(2.0) * (REG ? ckcodtla : ckcodtl) / sq(lcrit)) * ltmp4 * cldl * cldl_i;
+        const T rclc = frcp<T>(clc);
+        const T cldl = qlwc * rclc;
+        const T cldl_i = qlwc_i * rclc - qlwc * clc_i * rclc * rclc;
+        const T ltmp4 = fexp<T>(xk, -sq(cldl * kc.rlcrit));
+        const T dl = kc.ckcodtl * (T(1.0) - ltmp4);
+        const T ltmp5 = fexp<T>(xk, -dl);
+        const T dl_i = (T(2.0) * (REG ? kc.ckcodtl * T(0.01) : kc.ckcodtl) * kc.rlcrit * kc.rlcrit) * ltmp4 * cldl * cldl_i;
         const T qlnew = clc * cldl * ltmp5;
         const T qlnew_i = clc_i * cldl * ltmp5 + clc * cldl_i * ltmp5 - clc * cldl * ltmp5 * dl_i;
         prr = qlwc - qlnew;
         prr_i = qlwc_i - qlnew_i;
         qlwc -= prr;
         qlwc_i -= prr_i;
-        const T icrit = T(2.0) * e.RCLCRIT;
-        const T cldi = qiwc / clc;
-        const T cldi_i = qiwc_i / clc - qiwc * clc_i / sq(clc);
-        const T itmp41 = rexp<T>(-sq(cldi / icrit));
-        const T itmp42 = rexp<T>(T(0.025) * (t - e.RTT));
-        const T di = ckcodti * itmp42 * (T(1.0) - itmp41);
-        const T itmp5 = rexp<T>(-di);
-        const T di_i = (REG ? ckcodtia : ckcodti) * itmp42 *
-                       (itmp41 * (T(2.0) * cldi * cldi_i / sq(icrit) - T(0.025) * t_i) + T(0.025) * t_i);
+        const T cldi = qiwc * rclc;
+        const T cldi_i = qiwc_i * rclc - qiwc * clc_i * rclc * rclc;
+        const T itmp41 = fexp<T>(xk, -sq(cldi * kc.ricrit));
+        const T itmp42 = fexp<T>(xk, T(0.025) * (t - e.RTT));
+        const T di = kc.ckcodti * itmp42 * (T(1.0) - itmp41);
+        const T itmp5 = fexp<T>(xk, -di);
+        const T di_i = (REG ? kc.ckcodti * T(0.01) : kc.ckcodti) * itmp42 *
+                       (itmp41 * (T(2.0) * cldi * cldi_i * kc.ricrit * kc.ricrit - T(0.025) * t_i) + T(0.025) * t_i);
         const T qinew = clc * cldi * itmp5;
         const T qinew_i = clc_i * cldi * itmp5 + clc * cldi_i * itmp5 - clc * cldi * itmp5 * di_i;
         prs = qiwc - qinew;
@@ -325,27 +325,24 @@ __device__ __forceinline__ TLOut<T> tl_level(const Ext<T>& e, const TLIn<T>& x, 
         qiwc_i -= prs_i;
     }
     // :506-523 new precipitation
-    const T dr = cons2 * dp * (prr + prs);
-    const T dr_i = cons2 * (dp_i * (prr + prs) + dp * (prr_i + prs_i));
-    T rfreeze, rfreeze_i, fwatr;
+    const T dr = kc.cons2 * dp * (prr + prs);
+    const T dr_i = kc.cons2 * (dp_i * (prr + prs) + dp * (prr_i + prs_i));
+    T rfreeze, rfreeze_i;
     if (t < e.RTT) {
-        rfreeze = cons2 * dp * prr;
-        rfreeze_i = cons2 * (dp_i * prr + dp * prr_i);
-        fwatr = T(0.0);
+        rfreeze = kc.cons2 * dp * prr;
+        rfreeze_i = kc.cons2 * (dp_i * prr + dp * prr_i);
+        sfln += dr;
+        sfln_i += dr_i;
     } else {
         rfreeze = T(0.0);
         rfreeze_i = T(0.0);
-        fwatr = T(1.0);
+        rfln += dr;
+        rfln_i += dr_i;
     }
-    rfln += fwatr * dr;
-    rfln_i += fwatr * dr_i;
-    sfln += (T(1.0) - fwatr) * dr;
-    sfln_i += (T(1.0) - fwatr) * dr_i;
     // :526-616 evaporation: not instantiated (evapr = evaps = 0)
     // :619-659
-    const T hh = x.lude * (fwat * lvdcp + (T(1.0) - fwat) * lsdcp);
-    const T hh_i = y.lude * (fwat * lvdcp + (T(1.0) - fwat) * lsdcp) +
-                   x.lude * (fwat_i * (lvdcp - lsdcp) + fwat * lvdcp_i + (T(1.0) - fwat) * lsdcp_i);
+    const T hh = x.lude * ldcp;
+    const T hh_i = y.lude * ldcp + x.lude * ldcp_i;
     const T dqdt = -(condl + condi) + x.lude * gdp;
     const T dqdt_i = -(condl_i + condi_i) + y.lude * gdp + x.lude * gdp_i;
     const T tmp7 = hh - (lsdcp - lvdcp) * rfreeze;
@@ -358,8 +355,17 @@ __device__ __forceinline__ TLOut<T> tl_level(const Ext<T>& e, const TLIn<T>& x, 
     q_i += dt * dqdt_i;
     const T qold = q;
     const T qold_i = q_i;
-    // :662
-    cuadjtqs_tl(e, x.ap, y.ap, t, t_i, q, q_i);
+    // :662 (tangent_linear/_stencils/cuadjtqs.py:55-84)
+    {
+        T a3, a4, a5, ad;
+        if (t > e.RTT) {
+            a3 = e.R3LES; a4 = e.R4LES; a5 = e.R5ALVCP; ad = e.RALVDCP;
+        } else {
+            a3 = e.R3IES; a4 = e.R4IES; a5 = e.R5ALSCP; ad = e.RALSDCP;
+        }
+        tl_cuadj_iter(e, xk, rap, y.ap, t, t_i, q, q_i, a3, a4, a5, ad);
+        tl_cuadj_iter(e, xk, rap, y.ap, t, t_i, q, q_i, a3, a4, a5, ad);
+    }
     // :664-673
     T dq, dq_i;
     if (qold >= q) {
@@ -370,29 +376,22 @@ __device__ __forceinline__ TLOut<T> tl_level(const Ext<T>& e, const TLIn<T>& x, 
         dq = T(0.0);
         dq_i = T(0.0);
     }
-    const T dr2 = cons2 * dp * dq;
-    const T dr2_i = cons2 * (dp_i * dq + dp * dq_i);
+    const T dr2 = kc.cons2 * dp * dq;
+    const T dr2_i = kc.cons2 * (dp_i * dq + dp * dq_i);
     // :677-703
-    T rfreeze2, rfreeze2_i;
     if (t < e.RTT) {
-        rfreeze2 = fwat * dr2;
-        rfreeze2_i = fwat_i * dr2 + fwat * dr2_i;
-        fwatr = T(0.0);
+        rfreeze += fwat * dr2;
+        rfreeze_i += fwat_i * dr2 + fwat * dr2_i;
+        condi += dq * kc.rdt;
+        condi_i += dq_i * kc.rdt;
+        sfln += dr2;
+        sfln_i += dr2_i;
     } else {
-        rfreeze2 = T(0.0);
-        rfreeze2_i = T(0.0);
-        fwatr = T(1.0);
+        condl += dq * kc.rdt;
+        condl_i += dq_i * kc.rdt;
+        rfln += dr2;
+        rfln_i += dr2_i;
     }
-    condl += fwatr * dq / dt;
-    condl_i += fwatr * dq_i / dt;
-    condi += (T(1.0) - fwatr) * dq / dt;
-    condi_i += (T(1.0) - fwatr) * dq_i / dt;
-    rfln += fwatr * dr2;
-    rfln_i += fwatr * dr2_i;
-    sfln += (T(1.0) - fwatr) * dr2;
-    sfln_i += (T(1.0) - fwatr) * dr2_i;
-    rfreeze += rfreeze2;
-    rfreeze_i += rfreeze2_i;
     // :706-741
     o.clc = clc;
     o.clc_i = clc_i;
@@ -402,10 +401,10 @@ __device__ __forceinline__ TLOut<T> tl_level(const Ext<T>& e, const TLIn<T>& x, 
     o.tnd_t = lvdcp * condl + lsdcp * condi - tmp8 * gdp;
     o.tnd_t_i = lvdcp_i * condl + lvdcp * condl_i + lsdcp_i * condi + lsdcp * condi_i -
                 (hh_i - (lsdcp_i - lvdcp_i) * rfreeze - (lsdcp - lvdcp) * rfreeze_i) * gdp - tmp8 * gdp_i;
-    o.tnd_ql = (qlwc - ql) / dt;
-    o.tnd_ql_i = (qlwc_i - ql_i) / dt;
-    o.tnd_qi = (qiwc - qi) / dt;
-    o.tnd_qi_i = (qiwc_i - qi_i) / dt;
+    o.tnd_ql = (qlwc - ql) * kc.rdt;
+    o.tnd_ql_i = (qlwc_i - ql_i) * kc.rdt;
+    o.tnd_qi = (qiwc - qi) * kc.rdt;
+    o.tnd_qi_i = (qiwc_i - qi_i) * kc.rdt;
     // :744-753
     o.rfln = rfln;
     o.rfln_i = rfln_i;
@@ -422,40 +421,40 @@ __device__ __forceinline__ TLOut<T> tl_level(const Ext<T>& e, const TLIn<T>& x, 
 
 template <typename T>
 __device__ __forceinline__ void tl_store(const MPtrs<T, NL_NUM_OUT>& out, const MPtrs<T, NL_NUM_OUT>& out_i,
-                                         const Ext<T>& e, int64_t ls, int col, int k, const TLOut<T>& o) {
-    const int64_t i = int64_t(k) * ls + col;
-    out.p[NL_OUT_CLC][i] = o.clc;
-    out_i.p[NL_OUT_CLC][i] = o.clc_i;
-    out.p[NL_OUT_COVPTOT][i] = T(0.0);      // :185-186 (only the evaporation block sets it)
-    out_i.p[NL_OUT_COVPTOT][i] = T(0.0);
-    out.p[NL_OUT_TND_Q][i] = o.tnd_q;
-    out_i.p[NL_OUT_TND_Q][i] = o.tnd_q_i;
-    out.p[NL_OUT_TND_T][i] = o.tnd_t;
-    out_i.p[NL_OUT_TND_T][i] = o.tnd_t_i;
-    out.p[NL_OUT_TND_QL][i] = o.tnd_ql;
-    out_i.p[NL_OUT_TND_QL][i] = o.tnd_ql_i;
-    out.p[NL_OUT_TND_QI][i] = o.tnd_qi;
-    out_i.p[NL_OUT_TND_QI][i] = o.tnd_qi_i;
+                                         const Ext<T>& e, uint32_t lsb, uint32_t i, const TLOut<T>& o) {
+    stg(out.p[NL_OUT_CLC], i, o.clc);
+    stg(out_i.p[NL_OUT_CLC], i, o.clc_i);
+    stg(out.p[NL_OUT_COVPTOT], i, T(0.0));      // :185-186 (only the evaporation block sets it)
+    stg(out_i.p[NL_OUT_COVPTOT], i, T(0.0));
+    stg(out.p[NL_OUT_TND_Q], i, o.tnd_q);
+    stg(out_i.p[NL_OUT_TND_Q], i, o.tnd_q_i);
+    stg(out.p[NL_OUT_TND_T], i, o.tnd_t);
+    stg(out_i.p[NL_OUT_TND_T], i, o.tnd_t_i);
+    stg(out.p[NL_OUT_TND_QL], i, o.tnd_ql);
+    stg(out_i.p[NL_OUT_TND_QL], i, o.tnd_ql_i);
+    stg(out.p[NL_OUT_TND_QI], i, o.tnd_qi);
+    stg(out_i.p[NL_OUT_TND_QI], i, o.tnd_qi_i);
     // :766-774
-    out.p[NL_OUT_FPLSL][i + ls] = o.rfln;
-    out_i.p[NL_OUT_FPLSL][i + ls] = o.rfln_i;
-    out.p[NL_OUT_FPLSN][i + ls] = o.sfln;
-    out_i.p[NL_OUT_FPLSN][i + ls] = o.sfln_i;
-    out.p[NL_OUT_FHPSL][i + ls] = -o.rfln * e.RLVTT;
-    out_i.p[NL_OUT_FHPSL][i + ls] = -o.rfln_i * e.RLVTT;
-    out.p[NL_OUT_FHPSN][i + ls] = -o.sfln * e.RLSTT;
-    out_i.p[NL_OUT_FHPSN][i + ls] = -o.sfln_i * e.RLSTT;
+    stg(out.p[NL_OUT_FPLSL], i + lsb, o.rfln);
+    stg(out_i.p[NL_OUT_FPLSL], i + lsb, o.rfln_i);
+    stg(out.p[NL_OUT_FPLSN], i + lsb, o.sfln);
+    stg(out_i.p[NL_OUT_FPLSN], i + lsb, o.sfln_i);
+    stg(out.p[NL_OUT_FHPSL], i + lsb, -o.rfln * e.RLVTT);
+    stg(out_i.p[NL_OUT_FHPSL], i + lsb, -o.rfln_i * e.RLVTT);
+    stg(out.p[NL_OUT_FHPSN], i + lsb, -o.sfln * e.RLSTT);
+    stg(out_i.p[NL_OUT_FHPSN], i + lsb, -o.sfln_i * e.RLSTT);
 }
 
 template <typename T>
-__device__ __forceinline__ T tl_trpaus(const T* __restrict__ pt, const T* __restrict__ ptt, int64_t ls, int col,
-                                       T dt, const T* s_eta, int klo, int khi) {
+__device__ __forceinline__ T tl_trpaus(const T* __restrict__ pt, const T* __restrict__ ptt, uint32_t lsb,
+                                       uint32_t colb, T dt, const T* s_eta, int klo, int khi) {
     T trpaus = T(0.1);
     if (klo <= khi) {
-        T tk = pt[int64_t(klo) * ls + col] + dt * ptt[int64_t(klo) * ls + col];
+        uint32_t o = uint32_t(klo) * lsb + colb;
+        T tk = ldg(pt, o) + dt * ldg(ptt, o);
         for (int k = klo; k <= khi; ++k) {
-            const int64_t o1 = int64_t(k + 1) * ls + col;
-            const T tk1 = pt[o1] + dt * ptt[o1];
+            o += lsb;
+            const T tk1 = ldg(pt, o) + dt * ldg(ptt, o);
             const T ek = s_eta[k];
             if (ek > T(0.1) && ek < T(0.4) && tk > tk1) trpaus = ek;
             tk = tk1;
@@ -466,59 +465,65 @@ __device__ __forceinline__ T tl_trpaus(const T* __restrict__ pt, const T* __rest
 
 template <typename T, bool REG>
 __global__ void __launch_bounds__(kWave)
-tl_kernel(Ext<T> e, int nx, int nz, int64_t ls, CPtrs<T, NL_NUM_IN> in, CPtrs<T, NL_NUM_IN> in_i,
-          const T* __restrict__ eta, MPtrs<T, NL_NUM_OUT> out, MPtrs<T, NL_NUM_OUT> out_i, T dt) {
+tl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, NL_NUM_IN> in,
+          CPtrs<T, NL_NUM_IN> in_i, const T* __restrict__ eta, MPtrs<T, NL_NUM_OUT> out, MPtrs<T, NL_NUM_OUT> out_i,
+          T dt) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     T* s_eta = reinterpret_cast<T*>(smem_raw);
     T* s_scalm = s_eta + (nz + 1);
     int klo, khi;
     build_level_table<T>(eta, nz, e, s_eta, s_scalm, klo, khi);
+    if constexpr (sizeof(T) == 8) {
+        // fp64 constants of the level loop -> VGPRs (see pin_vgpr in cloudsc2_common.hpp)
+        pin_vgpr(e.RCPD); pin_vgpr(e.RLSTT); pin_vgpr(e.RLVTT); pin_vgpr(e.RLMLT); pin_vgpr(e.R4LES);
+        pin_vgpr(e.R4IES); pin_vgpr(e.RTT); pin_vgpr(e.R3IES); pin_vgpr(e.R3LES); pin_vgpr(e.R2ES);
+        pin_vgpr(e.ZQMAX); pin_vgpr(e.RETV); pin_vgpr(e.R5LES); pin_vgpr(e.R5IES); pin_vgpr(e.RG);
+        pin_vgpr(e.RD); pin_vgpr(kc.rdt); pin_vgpr(kc.cons2); pin_vgpr(kc.rRD); pin_vgpr(kc.rRCPD); pin_vgpr(dt);
+        pin_vgpr(xk.l2e); pin_vgpr(xk.ln2h); pin_vgpr(xk.ln2l); pin_vgpr(xk.c12); pin_vgpr(xk.c11);
+        pin_vgpr(xk.c10); pin_vgpr(xk.c9); pin_vgpr(xk.c8); pin_vgpr(xk.c7); pin_vgpr(xk.c6);
+        pin_vgpr(xk.c5); pin_vgpr(xk.c4); pin_vgpr(xk.c3);
+    }
 
     const int gcol = blockIdx.x * kWave + threadIdx.x;
     const bool live = gcol < nx;
     const int col = live ? gcol : nx - 1;
+    const uint32_t lsb = uint32_t(ls) * uint32_t(sizeof(T));
+    const uint32_t colb = uint32_t(col) * uint32_t(sizeof(T));
 
-    const T trpaus = tl_trpaus<T>(in.p[NL_IN_T], in.p[NL_IN_TND_CML_T], ls, col, dt, s_eta, klo, khi);
+    const T trpaus = tl_trpaus<T>(in.p[NL_IN_T], in.p[NL_IN_TND_CML_T], lsb, colb, dt, s_eta, klo, khi);
     const CrhCol<T> crh = crh_setup<T>(trpaus);
 
     // :124-135
     TLCarry<T> c;
     c.rfl = c.rfl_i = c.sfl = c.sfl_i = c.covptot = c.covptot_i = T(0.0);
-    c.aph_k = in.p[NL_IN_APH][col];
-    c.aph_k_i = in_i.p[NL_IN_APH][col];
+    c.aph_k = ldg(in.p[NL_IN_APH], colb);
+    c.aph_k_i = ldg(in_i.p[NL_IN_APH], colb);
 
     if (live) {
         // :757-765
-        out.p[NL_OUT_FPLSL][col] = T(0.0);
-        out_i.p[NL_OUT_FPLSL][col] = T(0.0);
-        out.p[NL_OUT_FPLSN][col] = T(0.0);
-        out_i.p[NL_OUT_FPLSN][col] = T(0.0);
-        out.p[NL_OUT_FHPSL][col] = T(0.0);
-        out_i.p[NL_OUT_FHPSL][col] = T(0.0);
-        out.p[NL_OUT_FHPSN][col] = T(0.0);
-        out_i.p[NL_OUT_FHPSN][col] = T(0.0);
+        stg(out.p[NL_OUT_FPLSL], colb, T(0.0));
+        stg(out_i.p[NL_OUT_FPLSL], colb, T(0.0));
+        stg(out.p[NL_OUT_FPLSN], colb, T(0.0));
+        stg(out_i.p[NL_OUT_FPLSN], colb, T(0.0));
+        stg(out.p[NL_OUT_FHPSL], colb, T(0.0));
+        stg(out_i.p[NL_OUT_FHPSL], colb, T(0.0));
+        stg(out.p[NL_OUT_FHPSN], colb, T(0.0));
+        stg(out_i.p[NL_OUT_FHPSN], colb, T(0.0));
     }
 
-    TLIn<T> xa = tl_load<T>(in, ls, col, 0), ya = tl_load<T>(in_i, ls, col, 0);
-    TLIn<T> xb = xa, yb = ya;
-    for (int k = 0; k < nz; k += 2) {
-        const bool has_b = (k + 1 < nz);
-        if (has_b) {
-            xb = tl_load<T>(in, ls, col, k + 1);
-            yb = tl_load<T>(in_i, ls, col, k + 1);
+    uint32_t o = colb;
+    TLIn<T> xa = tl_load<T>(in, lsb, o), ya = tl_load<T>(in_i, lsb, o);
+    for (int k = 0; k < nz; ++k) {
+        TLIn<T> xn = xa, yn = ya;
+        if (k + 1 < nz) {
+            xn = tl_load<T>(in, lsb, o + lsb);
+            yn = tl_load<T>(in_i, lsb, o + lsb);
         }
-        {
-            const TLOut<T> o = tl_level<T, REG>(e, xa, ya, k, s_eta[k], s_scalm[k], crh, dt, c);
-            if (live) tl_store<T>(out, out_i, e, ls, col, k, o);
-        }
-        if (has_b) {
-            if (k + 2 < nz) {
-                xa = tl_load<T>(in, ls, col, k + 2);
-                ya = tl_load<T>(in_i, ls, col, k + 2);
-            }
-            const TLOut<T> o = tl_level<T, REG>(e, xb, yb, k + 1, s_eta[k + 1], s_scalm[k + 1], crh, dt, c);
-            if (live) tl_store<T>(out, out_i, e, ls, col, k + 1, o);
-        }
+        const TLOut<T> r = tl_level<T, REG>(e, kc, xk, xa, ya, k, s_eta[k], s_scalm[k], crh, dt, c);
+        if (live) tl_store<T>(out, out_i, e, lsb, o, r);
+        xa = xn;
+        ya = yn;
+        o += lsb;
     }
 }
 
@@ -534,10 +539,15 @@ int launch_tl(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
     const dim3 grid((nx + kWave - 1) / kWave), block(kWave);
     const size_t smem = 2 * size_t(nz + 1) * sizeof(T);
     const T tdt = static_cast<T>(dt);
+    const NLK<T> kc = make_nlk<T>(p, dt, false);
+    const ExpK<T> xk = make_expk<T>();
+    if (!fits_u32_offsets<T>(nz, ls)) return -2;
     if (p.LREGCL)
-        hipLaunchKernelGGL((tl_kernel<T, true>), grid, block, smem, stream, e, nx, nz, ls, ci, cii, eta, co, coi, tdt);
+        hipLaunchKernelGGL((tl_kernel<T, true>), grid, block, smem, stream, e, kc, xk, nx, nz, ls, ci, cii, eta, co,
+                           coi, tdt);
     else
-        hipLaunchKernelGGL((tl_kernel<T, false>), grid, block, smem, stream, e, nx, nz, ls, ci, cii, eta, co, coi, tdt);
+        hipLaunchKernelGGL((tl_kernel<T, false>), grid, block, smem, stream, e, kc, xk, nx, nz, ls, ci, cii, eta, co,
+                           coi, tdt);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

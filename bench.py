@@ -81,6 +81,21 @@ def cpu_baseline(cols: int, nz: int, np_dtype, budget_s: float = 12.0):
     }
 
 
+class _StdoutToStderr:
+    """RCCL prints a version banner on STDOUT when a communicator is created; the bench contract is
+    ONE JSON line on stdout, so fd 1 is pointed at stderr while the communicator comes up."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
 def main():
     args = parse_args()
     import numpy as np
@@ -107,10 +122,15 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:
+        # one process per GPU under torch.distributed.run; backend "nccl" is RCCL on ROCm.  (Also taken
+        # for a 1-rank torchrun launch, which exercises the collective code path on a single GPU.)
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=device)
+        with _StdoutToStderr():
+            dist.init_process_group("nccl", device_id=device)
+            dist.barrier()          # creates the RCCL communicator (and prints its banner) now
+            torch.cuda.synchronize()
 
     np_dtype = np.float64 if args.precision == "double" else np.float32
     wsize = np.dtype(np_dtype).itemsize

@@ -23,38 +23,40 @@ __device__ __forceinline__ T foealfcu(const Ext<T>& e, T t) {
 // MODE 0: LPHYLIN; MODE 1: not LPHYLIN, KFLAG == 1 (f_foeewmcu); MODE 2: not LPHYLIN, KFLAG != 1 (f_foeewm)
 template <typename T, int MODE>
 __global__ void __launch_bounds__(kAuxBlock)
-saturation_kernel(Ext<T> e, int nx, int64_t ls, const T* __restrict__ ap, const T* __restrict__ t,
+saturation_kernel(Ext<T> e, ExpK<T> xk, int nx, int64_t ls, const T* __restrict__ ap, const T* __restrict__ t,
                   T* __restrict__ qsat) {
     const int col = blockIdx.x * kAuxBlock + threadIdx.x;
     if (col >= nx) return;
     const int64_t i = int64_t(blockIdx.y) * ls + col;
     const T tt = t[i];
-    const T foeewl = rexp<T>(e.R3LES * (tt - e.RTT) / (tt - e.R4LES));
-    const T foeewi = rexp<T>(e.R3IES * (tt - e.RTT) / (tt - e.R4IES));
+    const T rap = frcp<T>(ap[i]);
+    const T foeewl = fexp<T>(xk, e.R3LES * (tt - e.RTT) * frcp<T>(tt - e.R4LES));
+    const T foeewi = fexp<T>(xk, e.R3IES * (tt - e.RTT) * frcp<T>(tt - e.R4IES));
     T qs;
     if constexpr (MODE == 0) {
         const T alfa = foealfa(e, tt);
         const T foeew = alfa * (e.R2ES * foeewl) + (T(1.0) - alfa) * (e.R2ES * foeewi);
-        qs = rmin<T>(foeew / ap[i], e.QMAX);
+        qs = rmin<T>(foeew * rap, e.QMAX);
     } else {
         const T alfa = (MODE == 1) ? foealfcu(e, tt) : foealfa(e, tt);
         const T ew = e.R2ES * (alfa * foeewl + (T(1.0) - alfa) * foeewi);
-        qs = rmin<T>(ew / ap[i], e.QMAX);
+        qs = rmin<T>(ew * rap, e.QMAX);
     }
-    qsat[i] = qs / (T(1.0) - e.RETV * qs);
+    qsat[i] = qs * frcp<T>(T(1.0) - e.RETV * qs);
 }
 
 template <typename T>
 int launch_saturation(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* ap, const T* t,
                       T* qsat, hipStream_t stream) {
     const Ext<T> e = make_ext<T>(p);
+    const ExpK<T> xk = make_expk<T>();
     const dim3 grid((nx + kAuxBlock - 1) / kAuxBlock, nz), block(kAuxBlock);
     if (p.LPHYLIN)
-        hipLaunchKernelGGL((saturation_kernel<T, 0>), grid, block, 0, stream, e, nx, ls, ap, t, qsat);
+        hipLaunchKernelGGL((saturation_kernel<T, 0>), grid, block, 0, stream, e, xk, nx, ls, ap, t, qsat);
     else if (p.KFLAG == 1)
-        hipLaunchKernelGGL((saturation_kernel<T, 1>), grid, block, 0, stream, e, nx, ls, ap, t, qsat);
+        hipLaunchKernelGGL((saturation_kernel<T, 1>), grid, block, 0, stream, e, xk, nx, ls, ap, t, qsat);
     else
-        hipLaunchKernelGGL((saturation_kernel<T, 2>), grid, block, 0, stream, e, nx, ls, ap, t, qsat);
+        hipLaunchKernelGGL((saturation_kernel<T, 2>), grid, block, 0, stream, e, xk, nx, ls, ap, t, qsat);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

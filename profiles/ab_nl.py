@@ -43,18 +43,36 @@ def main():
     p = make_params(ext)
     s = make_state(nx, nz, dtype=np_dtype, device=dev)
     eta = torch.as_tensor(eta_levels(nz, dtype=np_dtype), device=dev)
-    f = {"in_" + k[2:]: storage.logical_view(v) for k, v in s.items()}
-    f["in_qsat"] = storage.zeros(nx, nz, np_dtype, dev)
+    arena = int(opts.get("arena", 0))
+    ls = nx
+    if arena:
+        # one allocation [level][slot][column] for all 26 fields of the call: lev_stride = slots * nx
+        slots = 26
+        ls = slots * nx
+        big = torch.zeros((nz + 1, slots, nx), dtype=storage.torch_dtype(np_dtype), device=dev)
+        names = [k for k in s] + ["f_qsat"]
+        f = {}
+        for i, k in enumerate(names):
+            if k in s:
+                big[:, i, :] = s[k]
+            f["in_" + k[2:]] = storage.logical_view(big[:, i, :])
+        out_base = len(names)
+    else:
+        f = {"in_" + k[2:]: storage.logical_view(v) for k, v in s.items()}
+        f["in_qsat"] = storage.zeros(nx, nz, np_dtype, dev)
     first = next(iter(libs.values()))
-    getattr(first, "cloudsc2_saturation_" + sfx)(ctypes.byref(p), nx, nz, nx, f["in_ap"].data_ptr(), f["in_t"].data_ptr(),
+    getattr(first, "cloudsc2_saturation_" + sfx)(ctypes.byref(p), nx, nz, ls, f["in_ap"].data_ptr(), f["in_t"].data_ptr(),
                                    f["in_qsat"].data_ptr(), None)
-    outs = {n: storage.zeros(nx, nz, np_dtype, dev) for n in NL_OUT}
+    if arena:
+        outs = {n: storage.logical_view(big[:, out_base + i, :]) for i, n in enumerate(NL_OUT)}
+    else:
+        outs = {n: storage.zeros(nx, nz, np_dtype, dev) for n in NL_OUT}
     pin = _lib.ptr_array([f["in_" + n].data_ptr() for n in NL_IN])
     pout = _lib.ptr_array([outs[n].data_ptr() for n in NL_OUT])
     stream = torch.cuda.current_stream().cuda_stream
 
     def call(lib):
-        rc = getattr(lib, "cloudsc2_nl_" + sfx)(ctypes.byref(p), nx, nz, nx, pin, eta.data_ptr(), pout, 3600.0, stream)
+        rc = getattr(lib, "cloudsc2_nl_" + sfx)(ctypes.byref(p), nx, nz, ls, pin, eta.data_ptr(), pout, 3600.0, stream)
         assert rc == 0, rc
 
     ref = None

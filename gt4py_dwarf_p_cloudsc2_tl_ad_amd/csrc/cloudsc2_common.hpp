@@ -136,13 +136,29 @@ __device__ __forceinline__ void pin_vgpr(T& x) {
 // Field access by 32-bit BYTE offset from a uniform base pointer: hipcc then emits the
 // `global_load_dwordx2 v, v_off, s[base:base+1]` form (no per-access 64-bit VALU address arithmetic).
 // The launchers guarantee (nz+1) * lev_stride * sizeof(T) < 2^32.
+// CS2_NT (bit 0: loads, bit 1: stores) selects non-temporal accesses: every field element is touched
+// exactly once per launch, and streaming reads/writes that do not linger in L2 measured faster on the
+// mixed 16-read / 10-write stream pattern (profiles/microbench_stream.hip; A/B in profiles/ab_nl.py).
+#ifndef CS2_NT
+#define CS2_NT 3
+#endif
 template <typename T>
 __device__ __forceinline__ T ldg(const T* base, uint32_t boff) {
-    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + boff);
+    const T* a = reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + boff);
+#if CS2_NT & 1
+    return __builtin_nontemporal_load(a);
+#else
+    return *a;
+#endif
 }
 template <typename T>
 __device__ __forceinline__ void stg(T* base, uint32_t boff, T v) {
-    *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + boff) = v;
+    T* a = reinterpret_cast<T*>(reinterpret_cast<char*>(base) + boff);
+#if CS2_NT & 2
+    __builtin_nontemporal_store(v, a);
+#else
+    *a = v;
+#endif
 }
 template <typename T>
 inline bool fits_u32_offsets(int nz, int64_t ls) {

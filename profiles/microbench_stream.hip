@@ -20,7 +20,7 @@ struct Ptrs {
     double* out[NF_OUT];
 };
 
-template <int MODE>
+template <int MODE, int NT = 0>
 __global__ void __launch_bounds__(64) stream_kernel(Ptrs p, int nx, int nlev, unsigned lsb) {
     const int lane = threadIdx.x;
     const int col0 = blockIdx.x * 64;
@@ -31,11 +31,17 @@ __global__ void __launch_bounds__(64) stream_kernel(Ptrs p, int nx, int nlev, un
             double s = acc;
             if constexpr (MODE != 5) {
 #pragma unroll
-                for (int f = 0; f < NF_IN; ++f) s += *reinterpret_cast<const double*>(reinterpret_cast<const char*>(p.in[f]) + o);
+                for (int f = 0; f < NF_IN; ++f) {
+                    const double* a = reinterpret_cast<const double*>(reinterpret_cast<const char*>(p.in[f]) + o);
+                    s += (NT & 1) ? __builtin_nontemporal_load(a) : *a;
+                }
             }
             if constexpr (MODE != 3) {
 #pragma unroll
-                for (int f = 0; f < NF_OUT; ++f) *reinterpret_cast<double*>(reinterpret_cast<char*>(p.out[f]) + o) = s + f;
+                for (int f = 0; f < NF_OUT; ++f) {
+                    double* a = reinterpret_cast<double*>(reinterpret_cast<char*>(p.out[f]) + o);
+                    if (NT & 2) __builtin_nontemporal_store(s + f, a); else *a = s + f;
+                }
             }
             acc = s * 1e-3;
             o += lsb;
@@ -72,14 +78,14 @@ __global__ void __launch_bounds__(64) stream_kernel(Ptrs p, int nx, int nlev, un
     if (acc == 12345.678) p.out[0][col0 + lane] = acc;  // keep loads alive in load-only modes
 }
 
-template <int MODE>
+template <int MODE, int NT = 0>
 float run(const Ptrs& p, int nx, int nlev, int iters, unsigned lsb) {
     hipEvent_t a, b;
     hipEventCreate(&a);
     hipEventCreate(&b);
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(stream_kernel<MODE>, dim3(nx / 64), dim3(64), 0, 0, p, nx, nlev, lsb);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((stream_kernel<MODE, NT>), dim3(nx / 64), dim3(64), 0, 0, p, nx, nlev, lsb);
     hipEventRecord(a);
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(stream_kernel<MODE>, dim3(nx / 64), dim3(64), 0, 0, p, nx, nlev, lsb);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((stream_kernel<MODE, NT>), dim3(nx / 64), dim3(64), 0, 0, p, nx, nlev, lsb);
     hipEventRecord(b);
     hipEventSynchronize(b);
     float ms;
@@ -106,6 +112,10 @@ int main(int argc, char** argv) {
         r[5] = {"8B stores only        ", run<5>(p, nx, nlev, 20, lsb), wr};
         r[6] = {"16B stores only       ", run<6>(p, nx, nlev, 20, lsb), wr};
         printf("separate allocations, [level][column] each:\n");
+        R n1 = {"8B nt-loads + 8B stores ", run<0, 1>(p, nx, nlev, 20, lsb), rd + wr};
+        R n2 = {"8B loads + 8B nt-stores ", run<0, 2>(p, nx, nlev, 20, lsb), rd + wr};
+        R n3 = {"8B nt-loads + nt-stores ", run<0, 3>(p, nx, nlev, 20, lsb), rd + wr};
+        for (auto& x : {n1, n2, n3}) printf("  %s  %8.1f us  %7.1f GB/s\n", x.name, x.ms * 1e3, x.bytes / (x.ms * 1e-3) / 1e9);
         for (auto& x : r) printf("  %s  %8.1f us  %7.1f GB/s\n", x.name, x.ms * 1e3, x.bytes / (x.ms * 1e-3) / 1e9);
     }
     {

@@ -692,7 +692,7 @@ __device__ __forceinline__ T ad_trpaus(const T* __restrict__ pt, const T* __rest
 }
 
 template <typename T, bool REG, bool FIX>
-__global__ void __launch_bounds__(kWave)
+__global__ void __launch_bounds__(kColBlock)
 ad_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, NL_NUM_IN> in,
           CPtrs<T, NL_NUM_OUT> adj, const T* __restrict__ eta, MPtrs<T, NL_NUM_OUT> out, MPtrs<T, NL_NUM_IN> oadj,
           T dt) {
@@ -712,7 +712,7 @@ ad_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
         pin_vgpr(xk.c5); pin_vgpr(xk.c4); pin_vgpr(xk.c3);
     }
 
-    const int gcol = blockIdx.x * kWave + threadIdx.x;
+    const int gcol = blockIdx.x * kColBlock + threadIdx.x;
     if (gcol >= nx) return;  // no later workgroup barrier: whole lanes may retire
     const uint32_t lsb = uint32_t(ls) * uint32_t(sizeof(T));
     const uint32_t colb = uint32_t(gcol) * uint32_t(sizeof(T));
@@ -819,7 +819,7 @@ int launch_ad(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
     MPtrs<T, NL_NUM_IN> coa;
     for (int i = 0; i < NL_NUM_IN; ++i) { ci.p[i] = in[i]; coa.p[i] = out_adj[i]; }
     for (int i = 0; i < NL_NUM_OUT; ++i) { ca.p[i] = in_adj[i]; co.p[i] = out[i]; }
-    const dim3 grid((nx + kWave - 1) / kWave), block(kWave);
+    const dim3 grid((nx + kColBlock - 1) / kColBlock), block(kColBlock);
     const size_t smem = 2 * size_t(nz + 1) * sizeof(T);
     const T tdt = static_cast<T>(dt);
     const NLK<T> kc = make_nlk<T>(p, dt, false);

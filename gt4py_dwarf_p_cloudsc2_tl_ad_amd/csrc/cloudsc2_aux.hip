@@ -28,8 +28,8 @@ saturation_kernel(Ext<T> e, ExpK<T> xk, int nx, int64_t ls, const T* __restrict_
     const int col = blockIdx.x * kAuxBlock + threadIdx.x;
     if (col >= nx) return;
     const int64_t i = int64_t(blockIdx.y) * ls + col;
-    const T tt = t[i];
-    const T rap = frcp<T>(ap[i]);
+    const T tt = ntload(t + i);
+    const T rap = frcp<T>(ntload(ap + i));
     const T foeewl = fexp<T>(xk, e.R3LES * (tt - e.RTT) * frcp<T>(tt - e.R4LES));
     const T foeewi = fexp<T>(xk, e.R3IES * (tt - e.RTT) * frcp<T>(tt - e.R4IES));
     T qs;
@@ -42,7 +42,7 @@ saturation_kernel(Ext<T> e, ExpK<T> xk, int nx, int64_t ls, const T* __restrict_
         const T ew = e.R2ES * (alfa * foeewl + (T(1.0) - alfa) * foeewi);
         qs = rmin<T>(ew * rap, e.QMAX);
     }
-    qsat[i] = qs * frcp<T>(T(1.0) - e.RETV * qs);
+    ntstore(qsat + i, qs * frcp<T>(T(1.0) - e.RETV * qs));
 }
 
 template <typename T>
@@ -68,12 +68,12 @@ increment_kernel(int nx, int64_t ls, CPtrs<T, INC_NUM> in, MPtrs<T, INC_NUM> out
     const int64_t i = int64_t(blockIdx.y) * ls + col;
     T v[INC_NUM];
 #pragma unroll
-    for (int n = 0; n < INC_NUM; ++n) v[n] = in.p[n][i];
+    for (int n = 0; n < INC_NUM; ++n) v[n] = ntload(in.p[n] + i);
 #pragma unroll
     for (int n = 0; n < INC_NUM; ++n) {
         T r = f * v[n];
         if (n == INC_SUPSAT && ignore_supsat) r = T(0.0);
-        out.p[n][i] = r;
+        ntstore(out.p[n] + i, r);
     }
 }
 
@@ -97,9 +97,9 @@ perturb_kernel(int nx, int64_t ls, CPtrs<T, INC_NUM> in, CPtrs<T, INC_NUM> in_i,
     const int64_t i = int64_t(blockIdx.y) * ls + col;
     T a[INC_NUM], b[INC_NUM];
 #pragma unroll
-    for (int n = 0; n < INC_NUM; ++n) { a[n] = in.p[n][i]; b[n] = in_i.p[n][i]; }
+    for (int n = 0; n < INC_NUM; ++n) { a[n] = ntload(in.p[n] + i); b[n] = ntload(in_i.p[n] + i); }
 #pragma unroll
-    for (int n = 0; n < INC_NUM; ++n) out.p[n][i] = a[n] + f * b[n];
+    for (int n = 0; n < INC_NUM; ++n) ntstore(out.p[n] + i, a[n] + f * b[n]);
 }
 
 template <typename T>

@@ -16,6 +16,15 @@
 namespace cs2 {
 
 constexpr int kWave = 64;  // CDNA wavefront
+// Workgroup of the column kernels: 4 waves = one per SIMD of a CU.  One-wave workgroups are placed
+// SIMD by SIMD by the dispatcher, and after a kernel with a very large grid (e.g. `saturation`) ~10 % of
+// them double up on a SIMD while other SIMDs stay empty (profiles/census_placement.hip), which cost
+// cloudsc2_nl +65 us in the driver loop; the 4 waves of a 256-thread workgroup always go to the 4
+// different SIMDs of their CU.
+#ifndef CS2_COL_BLOCK
+#define CS2_COL_BLOCK 256
+#endif
+constexpr int kColBlock = CS2_COL_BLOCK;
 
 // ---- math in the working precision --------------------------------------------------------
 template <typename T> __device__ __forceinline__ T rexp(T x);
@@ -154,6 +163,23 @@ __device__ __forceinline__ T ldg(const T* base, uint32_t boff) {
 template <typename T>
 __device__ __forceinline__ void stg(T* base, uint32_t boff, T v) {
     T* a = reinterpret_cast<T*>(reinterpret_cast<char*>(base) + boff);
+#if CS2_NT & 2
+    __builtin_nontemporal_store(v, a);
+#else
+    *a = v;
+#endif
+}
+// streaming access for the pointwise helper kernels (64-bit indexing, same CS2_NT policy)
+template <typename T>
+__device__ __forceinline__ T ntload(const T* a) {
+#if CS2_NT & 1
+    return __builtin_nontemporal_load(a);
+#else
+    return *a;
+#endif
+}
+template <typename T>
+__device__ __forceinline__ void ntstore(T* a, T v) {
 #if CS2_NT & 2
     __builtin_nontemporal_store(v, a);
 #else

@@ -342,7 +342,7 @@ __device__ __forceinline__ T nl_trpaus(const T* __restrict__ pt, const T* __rest
 }
 
 template <typename T, bool EVAP, bool LIN, bool PINK>
-__global__ void __launch_bounds__(kWave)
+__global__ void __launch_bounds__(kColBlock)
 nl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, NL_NUM_IN> in, const T* __restrict__ eta,
           MPtrs<T, NL_NUM_OUT> out, T dt) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -365,7 +365,7 @@ nl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
         pin_vgpr(xk.c5); pin_vgpr(xk.c4); pin_vgpr(xk.c3);
     }
 
-    const int gcol = blockIdx.x * kWave + threadIdx.x;
+    const int gcol = blockIdx.x * kColBlock + threadIdx.x;
 #if CS2_NL_DIAG == 2
     const bool live = gcol < nx && nz < 0;   // never true at run time: no stores
 #else
@@ -430,7 +430,7 @@ int launch_nl(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
     MPtrs<T, NL_NUM_OUT> co;
     for (int i = 0; i < NL_NUM_IN; ++i) ci.p[i] = in[i];
     for (int i = 0; i < NL_NUM_OUT; ++i) co.p[i] = out[i];
-    const dim3 grid((nx + kWave - 1) / kWave), block(kWave);
+    const dim3 grid((nx + kColBlock - 1) / kColBlock), block(kColBlock);
     const size_t smem = 2 * size_t(nz + 1) * sizeof(T);
     const bool evap = p.LEVAPLS2 || p.LDRAIN1D;
     const bool lin = p.LPHYLIN || p.LDRAIN1D;

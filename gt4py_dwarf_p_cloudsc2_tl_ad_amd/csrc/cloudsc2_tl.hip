@@ -464,7 +464,7 @@ __device__ __forceinline__ T tl_trpaus(const T* __restrict__ pt, const T* __rest
 }
 
 template <typename T, bool REG>
-__global__ void __launch_bounds__(kWave)
+__global__ void __launch_bounds__(kColBlock)
 tl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, NL_NUM_IN> in,
           CPtrs<T, NL_NUM_IN> in_i, const T* __restrict__ eta, MPtrs<T, NL_NUM_OUT> out, MPtrs<T, NL_NUM_OUT> out_i,
           T dt) {
@@ -484,7 +484,7 @@ tl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
         pin_vgpr(xk.c5); pin_vgpr(xk.c4); pin_vgpr(xk.c3);
     }
 
-    const int gcol = blockIdx.x * kWave + threadIdx.x;
+    const int gcol = blockIdx.x * kColBlock + threadIdx.x;
     const bool live = gcol < nx;
     const int col = live ? gcol : nx - 1;
     const uint32_t lsb = uint32_t(ls) * uint32_t(sizeof(T));
@@ -536,7 +536,7 @@ int launch_tl(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
     MPtrs<T, NL_NUM_OUT> co, coi;
     for (int i = 0; i < NL_NUM_IN; ++i) { ci.p[i] = in[i]; cii.p[i] = in_i[i]; }
     for (int i = 0; i < NL_NUM_OUT; ++i) { co.p[i] = out[i]; coi.p[i] = out_i[i]; }
-    const dim3 grid((nx + kWave - 1) / kWave), block(kWave);
+    const dim3 grid((nx + kColBlock - 1) / kColBlock), block(kColBlock);
     const size_t smem = 2 * size_t(nz + 1) * sizeof(T);
     const T tdt = static_cast<T>(dt);
     const NLK<T> kc = make_nlk<T>(p, dt, false);

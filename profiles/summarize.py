@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 CSV output (gpurun_out/prof_*) into the small summaries kept under profiles/rNN/.
+  python profiles/summarize.py <tag> <round-dir>     e.g.  python profiles/summarize.py r01d profiles/r01"""
+import collections, csv, glob, json, os, sys
+
+tag, out = sys.argv[1], sys.argv[2]
+os.makedirs(out, exist_ok=True)
+
+
+def stats(pattern, dest):
+    rows = []
+    for f in glob.glob(pattern):
+        rows += [r for r in csv.DictReader(open(f)) if "cs2::" in r["Name"]]
+    if rows:
+        with open(dest, "w", newline="") as o:
+            w = csv.DictWriter(o, fieldnames=list(rows[0].keys()))
+            w.writeheader()
+            w.writerows(rows)
+    return rows
+
+
+def pmc(pattern, dest):
+    pm = {}
+    for p in sorted(glob.glob(pattern)):
+        d = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(p)):
+            if "cs2::" in r["Kernel_Name"]:
+                d[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, v in d.items():
+            pm.setdefault(k, {}).update({c: {"mean_per_dispatch": sum(x) / len(x), "dispatches": len(x)} for c, x in v.items()})
+    json.dump(pm, open(dest, "w"), indent=1)
+    return pm
+
+
+for r in stats(f"gpurun_out/prof_all_{tag}/trace/runc/*kernel_stats.csv", f"{out}/all_kernels_fp64_65536_kernel_stats.csv"):
+    print("bench_kernels.py:", r["Name"].split("(")[0][:48], r["Calls"], round(float(r["AverageNs"]) / 1e3, 1), "us")
+for r in stats(f"gpurun_out/prof_{tag}/trace/runc/*kernel_stats.csv", f"{out}/nl_fp64_65536_kernel_stats.csv"):
+    print("bench.py        :", r["Name"].split("(")[0][:48], r["Calls"], round(float(r["AverageNs"]) / 1e3, 1), "us")
+pmc(f"gpurun_out/prof_all_{tag}/pmc_*/runc/*counter_collection.csv", f"{out}/all_kernels_fp64_65536_pmc.json")
+pm = pmc(f"gpurun_out/prof_{tag}/pmc_*/runc/*counter_collection.csv", f"{out}/nl_fp64_65536_pmc.json")
+for k, v in pm.items():
+    fs = v.get("FETCH_SIZE", {}).get("mean_per_dispatch", 0) * 1024
+    ws = v.get("WRITE_SIZE", {}).get("mean_per_dispatch", 0) * 1024
+    line = f"{k[:48]}: FETCH_SIZE x2 = {2 * fs / 1e9:.3f} GB, WRITE_SIZE = {ws / 1e9:.3f} GB"
+    if "SQ_INSTS_VALU" in v:
+        wc, va, wa = (v[c]["mean_per_dispatch"] for c in ("SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY"))
+        line += f", VALU/wave {v['SQ_INSTS_VALU']['mean_per_dispatch'] / v['SQ_WAVES']['mean_per_dispatch']:.0f}, VALU-active {va / wc:.0%}, waiting {wa / wc:.0%}"
+    print(line)

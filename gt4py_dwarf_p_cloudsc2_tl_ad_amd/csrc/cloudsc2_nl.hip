@@ -341,8 +341,11 @@ __device__ __forceinline__ T nl_trpaus(const T* __restrict__ pt, const T* __rest
     return trpaus;
 }
 
+#ifndef CS2_F32_WAVES
+#define CS2_F32_WAVES 1   // minimum waves per SIMD requested for the fp32 instantiations (register cap)
+#endif
 template <typename T, bool EVAP, bool LIN, bool PINK>
-__global__ void __launch_bounds__(kColBlock)
+__global__ void __launch_bounds__(kColBlock, (sizeof(T) == 4 ? CS2_F32_WAVES : 1))
 nl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, NL_NUM_IN> in, const T* __restrict__ eta,
           MPtrs<T, NL_NUM_OUT> out, T dt) {
     extern __shared__ __align__(16) unsigned char smem_raw[];

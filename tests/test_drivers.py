@@ -129,3 +129,43 @@ def test_config4_symmetry_test_65536(gpu, capsys):
     d = ctx["detail"]
     assert d["columns_passing"] / d["columns"] > 0.95, d     # reference-literal AD: only RTT-crossing columns fail
     print(capsys.readouterr().out)
+
+
+@pytest.mark.gpu
+def test_numpy_style_reductions_on_device_fields(gpu):
+    """The reference's harnesses call NumPy on `.data` slices (np.sum(field_tl), np.abs(np.sum(a - b)),
+    tangent_linear/validation.py:253-261; to_numpy(x)[:, 0, :], adjoint/validation.py:217-220).  With the hip
+    backend `.data` is a FieldTensor on the GPU: the reductions must run there and hand back host scalars."""
+    import torch
+
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd import storage
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.framework.fields import DataArray, FieldTensor, to_numpy
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.framework.grid import I, J, K
+
+    a = DataArray(storage.zeros(300, 137, np.float64, gpu), (I, J, K))
+    b = DataArray(storage.zeros(300, 137, np.float64, gpu), (I, J, K))
+    a.data.as_subclass(torch.Tensor).copy_(torch.rand(a.data.shape, dtype=torch.float64, device=gpu))
+    b.data.as_subclass(torch.Tensor).copy_(torch.rand(b.data.shape, dtype=torch.float64, device=gpu))
+    fa, fb = a.data[:, 0, :], b.data[:, 0, :]
+    assert isinstance(fa, FieldTensor) and fa.is_cuda
+    want = float(np.sum(to_numpy(a.data)[:, 0, :] - to_numpy(b.data)[:, 0, :]))
+    got = np.abs(np.sum(fa - fb))
+    assert isinstance(got, float) and abs(got - abs(want)) <= 1e-9 * max(1.0, abs(want))
+    den = np.abs(1e-3 * np.sum(fa))
+    assert den > 0 and isinstance(den, float)
+
+
+@pytest.mark.gpu
+def test_exec_info_and_stencil_csv_on_hip(gpu, tmp_path, capsys):
+    """`exec_info` bookkeeping through the hip stencils (HIP events) and the per-stencil CSV the drivers write
+    (run_nonlinear.py:221-232)."""
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.drivers import run_nonlinear
+
+    csv = tmp_path / "stencils.csv"
+    run_nonlinear.main(["--backend", "hip", "--num-cols", "4096", "--num-runs", "3", "--disable-validation",
+                        "--output-csv-file-stencils", str(csv)])
+    text = csv.read_text()
+    assert "cloudsc2_nl" in text and "saturation" in text
+    rows = [r.split(",") for r in text.strip().splitlines()[1:]]
+    for r in rows:
+        assert int(r[7]) == 3 and 0.0 < float(r[8]) < 50.0          # 3 timed calls each, a sane mean in ms

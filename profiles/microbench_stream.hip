@@ -78,6 +78,54 @@ __global__ void __launch_bounds__(64) stream_kernel(Ptrs p, int nx, int nlev, un
     if (acc == 12345.678) p.out[0][col0 + lane] = acc;  // keep loads alive in load-only modes
 }
 
+// Column-blocked layouts: every wave streams contiguous memory.
+//   BLK 0: per field [block][level][64 columns]   (26 contiguous 70-KB runs per wave)
+//   BLK 1: one arena [block][level][field][64]     (one contiguous 1.8-MB run per wave; `in` and `out` arenas)
+template <int BLK>
+__global__ void __launch_bounds__(256) blocked_kernel(Ptrs p, int nx, int nlev) {
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    double acc = 0.0;
+    if (BLK == 0) {
+        size_t o = size_t(wave) * (nlev + 1) * 64 + lane;
+        for (int k = 0; k < nlev; ++k) {
+            double s = acc;
+#pragma unroll
+            for (int f = 0; f < NF_IN; ++f) s += __builtin_nontemporal_load(p.in[f] + o);
+#pragma unroll
+            for (int f = 0; f < NF_OUT; ++f) __builtin_nontemporal_store(s + f, p.out[f] + o);
+            acc = s * 1e-3;
+            o += 64;
+        }
+    } else {
+        size_t oi = size_t(wave) * (nlev + 1) * NF_IN * 64 + lane, oo = size_t(wave) * (nlev + 1) * NF_OUT * 64 + lane;
+        for (int k = 0; k < nlev; ++k) {
+            double s = acc;
+#pragma unroll
+            for (int f = 0; f < NF_IN; ++f) s += __builtin_nontemporal_load(p.in[0] + oi + f * 64);
+#pragma unroll
+            for (int f = 0; f < NF_OUT; ++f) __builtin_nontemporal_store(s + f, p.out[0] + oo + f * 64);
+            acc = s * 1e-3;
+            oi += NF_IN * 64;
+            oo += NF_OUT * 64;
+        }
+    }
+    if (acc == 12345.678) p.out[0][lane] = acc;
+}
+template <int BLK>
+float run_blocked(const Ptrs& p, int nx, int nlev, int iters) {
+    hipEvent_t a, b;
+    hipEventCreate(&a);
+    hipEventCreate(&b);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(blocked_kernel<BLK>, dim3(nx / 256), dim3(256), 0, 0, p, nx, nlev);
+    hipEventRecord(a);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(blocked_kernel<BLK>, dim3(nx / 256), dim3(256), 0, 0, p, nx, nlev);
+    hipEventRecord(b);
+    hipEventSynchronize(b);
+    float ms;
+    hipEventElapsedTime(&ms, a, b);
+    return ms / iters;
+}
+
 template <int MODE, int NT = 0>
 float run(const Ptrs& p, int nx, int nlev, int iters, unsigned lsb) {
     hipEvent_t a, b;
@@ -142,6 +190,20 @@ int main(int argc, char** argv) {
         r[3] = {"8B stores only        ", run<5>(q, nx, nlev, 20, lsb), wr};
         printf("arena [level][field][column]:\n");
         for (auto& x : r) printf("  %s  %8.1f us  %7.1f GB/s\n", x.name, x.ms * 1e3, x.bytes / (x.ms * 1e-3) / 1e9);
+    }
+    {
+        R r0 = {"blocked per field [blk][lev][64]        ", run_blocked<0>(p, nx, nlev, 20), rd + wr};
+        Ptrs q;
+        double *ain, *aout;
+        hipMalloc((void**)&ain, bytes * NF_IN);
+        hipMalloc((void**)&aout, bytes * NF_OUT);
+        hipMemset(ain, 0, bytes * NF_IN);
+        hipMemset(aout, 0, bytes * NF_OUT);
+        for (int f = 0; f < NF_IN; ++f) q.in[f] = ain;
+        for (int f = 0; f < NF_OUT; ++f) q.out[f] = aout;
+        R r1 = {"blocked arena [blk][lev][field][64]     ", run_blocked<1>(q, nx, nlev, 20), rd + wr};
+        printf("column-blocked layouts (256-thread workgroups, nt loads + stores):\n");
+        for (auto& x : {r0, r1}) printf("  %s  %8.1f us  %7.1f GB/s\n", x.name, x.ms * 1e3, x.bytes / (x.ms * 1e-3) / 1e9);
     }
     return 0;
 }

@@ -24,6 +24,7 @@ INC_NUM = 16
 EXPORTED_SYMBOLS = (
     "cloudsc2_abi_version", "cloudsc2_params_sizeof", "cloudsc2_last_error", "cloudsc2_device_count",
     "cloudsc2_nl_f64", "cloudsc2_nl_f32",
+    "cloudsc2_nl_fused_f64", "cloudsc2_nl_fused_f32",
     "cloudsc2_tl_f64", "cloudsc2_tl_f32",
     "cloudsc2_ad_f64", "cloudsc2_ad_f32",
     "cloudsc2_saturation_f64", "cloudsc2_saturation_f32",
@@ -55,6 +56,9 @@ def _declare(lib: ctypes.CDLL) -> None:
         f = getattr(lib, f"cloudsc2_nl_{sfx}")
         f.restype = c_int32
         f.argtypes = common + [parr, c_void_p, parr, c_double, c_void_p]
+        f = getattr(lib, f"cloudsc2_nl_fused_{sfx}")
+        f.restype = c_int32
+        f.argtypes = common + [parr, parr, c_double, c_void_p, c_void_p, parr, c_double, c_void_p]
         for name in ("tl", "ad"):
             f = getattr(lib, f"cloudsc2_{name}_{sfx}")
             f.restype = c_int32

@@ -8,7 +8,8 @@
 
 namespace cs2 {
 template <typename T>
-int launch_nl(const Cloudsc2Params&, int, int, int64_t, const T* const*, const T*, T* const*, double, hipStream_t);
+int launch_nl(const Cloudsc2Params&, int, int, int64_t, const T* const*, const T*, T* const*, double, hipStream_t,
+              const T* const*, double, T*);
 template <typename T>
 int launch_tl(const Cloudsc2Params&, int, int, int64_t, const T* const*, const T* const*, const T*, T* const*,
               T* const*, double, hipStream_t);
@@ -68,7 +69,31 @@ int nl_impl(const char* fn, const Cloudsc2Params* p, int32_t nx, int32_t nz, int
     if (p->ICALL != 0) return fail(CLOUDSC2_E_UNSUPPORTED, "%s: ICALL=%d (the reference implements ICALL == 0 only)", fn, p->ICALL);
     if (!(dt > 0.0)) return fail(CLOUDSC2_E_ARG, "%s: dt=%g must be > 0", fn, dt);
     if (nx == 0) return CLOUDSC2_OK;
-    return launched(fn, cs2::launch_nl<T>(*p, nx, nz, ls, in, eta, out, dt, static_cast<hipStream_t>(stream)));
+    return launched(fn, cs2::launch_nl<T>(*p, nx, nz, ls, in, eta, out, dt, static_cast<hipStream_t>(stream), nullptr,
+                                          0.0, nullptr));
+}
+
+// Fused variants of cloudsc2_nl (build extensions): exactly one of `qsat_out` / `in_i` is non-NULL.
+template <typename T>
+int nl_fused_impl(const char* fn, const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls, const T* const* in,
+                  const T* const* in_i, double pf, T* qsat_out, const T* eta, T* const* out, double dt, void* stream) {
+    if (int rc = check_common(fn, p, nx, nz, ls)) return rc;
+    if (int rc = check_ptrs(fn, "out", const_cast<const T* const*>(out), NL_NUM_OUT)) return rc;
+    if (!in) return fail(CLOUDSC2_E_ARG, "%s: in is NULL", fn);
+    if ((qsat_out != nullptr) == (in_i != nullptr))
+        return fail(CLOUDSC2_E_ARG, "%s: exactly one of qsat_out (fused saturation) and in_i (fused perturbation) must be given", fn);
+    for (int i = 0; i < NL_NUM_IN; ++i)
+        if (!in[i] && !(qsat_out && i == NL_IN_QSAT)) return fail(CLOUDSC2_E_ARG, "%s: in[%d] is NULL", fn, i);
+    if (in_i)
+        if (int rc = check_ptrs(fn, "in_i", in_i, NL_NUM_IN)) return rc;
+    if (!eta) return fail(CLOUDSC2_E_ARG, "%s: eta is NULL", fn);
+    if (p->ICALL != 0) return fail(CLOUDSC2_E_UNSUPPORTED, "%s: ICALL=%d unsupported", fn, p->ICALL);
+    if (qsat_out && !p->LPHYLIN)
+        return fail(CLOUDSC2_E_UNSUPPORTED, "%s: only the LPHYLIN form of saturation is available fused", fn);
+    if (!(dt > 0.0)) return fail(CLOUDSC2_E_ARG, "%s: dt=%g must be > 0", fn, dt);
+    if (nx == 0) return CLOUDSC2_OK;
+    return launched(fn, cs2::launch_nl<T>(*p, nx, nz, ls, in, eta, out, dt, static_cast<hipStream_t>(stream), in_i, pf,
+                                          qsat_out));
 }
 
 template <typename T>
@@ -162,6 +187,16 @@ int32_t cloudsc2_nl_f64(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t
 int32_t cloudsc2_nl_f32(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls, const float* const* in,
                         const float* eta, float* const* out, double dt, void* stream) {
     return nl_impl<float>("cloudsc2_nl_f32", p, nx, nz, ls, in, eta, out, dt, stream);
+}
+int32_t cloudsc2_nl_fused_f64(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls, const double* const* in,
+                              const double* const* in_i, double pf, double* qsat_out, const double* eta,
+                              double* const* out, double dt, void* stream) {
+    return nl_fused_impl<double>("cloudsc2_nl_fused_f64", p, nx, nz, ls, in, in_i, pf, qsat_out, eta, out, dt, stream);
+}
+int32_t cloudsc2_nl_fused_f32(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls, const float* const* in,
+                              const float* const* in_i, double pf, float* qsat_out, const float* eta,
+                              float* const* out, double dt, void* stream) {
+    return nl_fused_impl<float>("cloudsc2_nl_fused_f32", p, nx, nz, ls, in, in_i, pf, qsat_out, eta, out, dt, stream);
 }
 int32_t cloudsc2_tl_f64(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls, const double* const* in,
                         const double* const* in_i, const double* eta, double* const* out, double* const* out_i,

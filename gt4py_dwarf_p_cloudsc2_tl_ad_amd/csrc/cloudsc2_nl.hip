@@ -50,7 +50,8 @@ struct NLIn {
 
 template <typename T>
 // `o` = byte offset of (level k, this lane's column); `lsb` = level stride in bytes.
-__device__ __forceinline__ NLIn<T> nl_load(const CPtrs<T, NL_NUM_IN>& in, uint32_t lsb, uint32_t o) {
+// SKIPQ: in_qsat is not read (the fused-saturation variant computes it).
+__device__ __forceinline__ NLIn<T> nl_load_impl(const CPtrs<T, NL_NUM_IN>& in, uint32_t lsb, uint32_t o, bool skipq) {
     NLIn<T> x;
     x.ap = ldg(in.p[NL_IN_AP], o);
     x.aph1 = ldg(in.p[NL_IN_APH], o + lsb);
@@ -61,7 +62,7 @@ __device__ __forceinline__ NLIn<T> nl_load(const CPtrs<T, NL_NUM_IN>& in, uint32
     x.q = ldg(in.p[NL_IN_Q], o);
     x.qi = ldg(in.p[NL_IN_QI], o);
     x.ql = ldg(in.p[NL_IN_QL], o);
-    x.qsat = ldg(in.p[NL_IN_QSAT], o);
+    x.qsat = skipq ? T(0.0) : ldg(in.p[NL_IN_QSAT], o);
     x.supsat = ldg(in.p[NL_IN_SUPSAT], o);
     x.t = ldg(in.p[NL_IN_T], o);
     x.tq = ldg(in.p[NL_IN_TND_CML_Q], o);
@@ -69,6 +70,34 @@ __device__ __forceinline__ NLIn<T> nl_load(const CPtrs<T, NL_NUM_IN>& in, uint32
     x.tql = ldg(in.p[NL_IN_TND_CML_QL], o);
     x.tt = ldg(in.p[NL_IN_TND_CML_T], o);
     return x;
+}
+
+template <typename T, bool SKIPQ>
+__device__ __forceinline__ NLIn<T> nl_load(const CPtrs<T, NL_NUM_IN>& in, uint32_t lsb, uint32_t o) {
+    return nl_load_impl<T>(in, lsb, o, SKIPQ);
+}
+
+// perturbed_state (common/_stencils/perturbed_state.py:75-91) applied on the fly: x + f * x_i.
+template <typename T>
+__device__ __forceinline__ NLIn<T> nl_perturb(const NLIn<T>& a, const NLIn<T>& b, T f) {
+    NLIn<T> x;
+    x.ap = a.ap + f * b.ap; x.aph1 = a.aph1 + f * b.aph1; x.lu1 = a.lu1 + f * b.lu1; x.lude = a.lude + f * b.lude;
+    x.mfd = a.mfd + f * b.mfd; x.mfu = a.mfu + f * b.mfu; x.q = a.q + f * b.q; x.qi = a.qi + f * b.qi;
+    x.ql = a.ql + f * b.ql; x.qsat = a.qsat + f * b.qsat; x.supsat = a.supsat + f * b.supsat; x.t = a.t + f * b.t;
+    x.tq = a.tq + f * b.tq; x.tqi = a.tqi + f * b.tqi; x.tql = a.tql + f * b.tql; x.tt = a.tt + f * b.tt;
+    return x;
+}
+
+// saturation, LPHYLIN form (common/_stencils/saturation.py:30-35,42 + f_foealfa, fcttre.py:22-27),
+// same arithmetic as cs2::saturation_kernel<T, 0>.
+template <typename T>
+__device__ __forceinline__ T nl_saturation(const Ext<T>& e, const ExpK<T>& xk, T ap, T t) {
+    const T alfa = rmin<T>(T(1.0), sq((rmax<T>(e.RTICE, rmin<T>(e.RTWAT, t)) - e.RTICE) * e.RTWAT_RTICE_R));
+    const T foeewl = fexp<T>(xk, e.R3LES * (t - e.RTT) * frcp<T>(t - e.R4LES));
+    const T foeewi = fexp<T>(xk, e.R3IES * (t - e.RTT) * frcp<T>(t - e.R4IES));
+    const T foeew = alfa * (e.R2ES * foeewl) + (T(1.0) - alfa) * (e.R2ES * foeewi);
+    const T qs = rmin<T>(foeew * frcp<T>(ap), e.QMAX);
+    return qs * frcp<T>(T(1.0) - e.RETV * qs);
 }
 
 template <typename T>
@@ -344,10 +373,18 @@ __device__ __forceinline__ T nl_trpaus(const T* __restrict__ pt, const T* __rest
 #ifndef CS2_F32_WAVES
 #define CS2_F32_WAVES 1   // minimum waves per SIMD requested for the fp32 instantiations (register cap)
 #endif
-template <typename T, bool EVAP, bool LIN, bool PINK>
+// FUSE selects the fused variants (build extensions; results identical to the
+// separate stencil calls):
+//   1  `saturation` fused in: in_qsat is not read but computed from (in_ap, in_t) exactly as
+//      common/_stencils/saturation.py:29-42 (LPHYLIN form) and written to `qsat_out` - the driver's
+//      timed region (saturation + cloudsc2_nl, run_nonlinear.py:117-118) becomes ONE launch;
+//   2  `perturbed_state` fused in: every input is read as in + pf * in_i
+//      (common/_stencils/perturbed_state.py:75-91) - the Taylor test's ten perturbed NL runs no longer
+//      write and re-read a perturbed copy of the 16-field state.
+template <typename T, bool EVAP, bool LIN, bool PINK, int FUSE>
 __global__ void __launch_bounds__(kColBlock, (sizeof(T) == 4 ? CS2_F32_WAVES : 1))
 nl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, NL_NUM_IN> in, const T* __restrict__ eta,
-          MPtrs<T, NL_NUM_OUT> out, T dt) {
+          MPtrs<T, NL_NUM_OUT> out, T dt, CPtrs<T, NL_NUM_IN> in_i, T pf, T* __restrict__ qsat_out) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     T* s_eta = reinterpret_cast<T*>(smem_raw);
     T* s_scalm = s_eta + (nz + 1);
@@ -404,20 +441,36 @@ nl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
 
     // Level sweep with a software prefetch ring of depth PD: while level k is computed, the inputs
     // of levels k+1 .. k+PD are in flight (one wave per SIMD at 65 536 columns: HBM latency can only
-    // hide behind this wave's own work, and ~1.6 us x 8 TB/s / 1024 waves wants > 1 level in flight).
+    // hide behind this wave's own work).
     constexpr int PD = CS2_NL_PREFETCH;
     NLIn<T> buf[PD + 1];
+    NLIn<T> bufi[FUSE == 2 ? PD + 1 : 1];
 #pragma unroll
-    for (int j = 0; j < PD; ++j) buf[j] = nl_load<T>(in, lsb, colb + uint32_t(j < nz ? j : 0) * lsb);
+    for (int j = 0; j < PD; ++j) {
+        const uint32_t oj = colb + uint32_t(j < nz ? j : 0) * lsb;
+        buf[j] = nl_load<T, FUSE == 1>(in, lsb, oj);
+        if constexpr (FUSE == 2) bufi[j] = nl_load<T, false>(in_i, lsb, oj);
+    }
     buf[PD] = buf[0];
+    if constexpr (FUSE == 2) bufi[PD] = bufi[0];
     uint32_t o = colb;  // byte offset of (level k, column)
     for (int k0 = 0; k0 < nz; k0 += PD + 1) {
 #pragma unroll
         for (int j = 0; j <= PD; ++j) {
             const int k = k0 + j;
             if (k < nz) {
-                if (k + PD < nz) buf[(j + PD) % (PD + 1)] = nl_load<T>(in, lsb, o + uint32_t(PD) * lsb);
-                const NLOut<T> r = nl_level<T, EVAP, LIN>(e, kc, xk, buf[j], s_eta[k], s_scalm[k], crh, dt, aph_s, c);
+                if (k + PD < nz) {
+                    buf[(j + PD) % (PD + 1)] = nl_load<T, FUSE == 1>(in, lsb, o + uint32_t(PD) * lsb);
+                    if constexpr (FUSE == 2)
+                        bufi[(j + PD) % (PD + 1)] = nl_load<T, false>(in_i, lsb, o + uint32_t(PD) * lsb);
+                }
+                NLIn<T> x = buf[j];
+                if constexpr (FUSE == 2) x = nl_perturb<T>(x, bufi[j], pf);
+                if constexpr (FUSE == 1) {
+                    x.qsat = nl_saturation<T>(e, xk, x.ap, x.t);
+                    if (live) stg(qsat_out, o, x.qsat);
+                }
+                const NLOut<T> r = nl_level<T, EVAP, LIN>(e, kc, xk, x, s_eta[k], s_scalm[k], crh, dt, aph_s, c);
                 if (live) nl_store<T>(out, e, lsb, o, r);
                 o += lsb;
             }
@@ -426,34 +479,48 @@ nl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
 }
 
 template <typename T>
-int launch_nl(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* const* in, const T* eta,
-              T* const* out, double dt, hipStream_t stream) {
+int launch_nl(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* const* in, const T* eta, T* const* out,
+              double dt, hipStream_t stream, const T* const* in_i = nullptr, double pf = 0.0, T* qsat_out = nullptr) {
     const Ext<T> e = make_ext<T>(p);
-    CPtrs<T, NL_NUM_IN> ci;
+    CPtrs<T, NL_NUM_IN> ci, cii;
     MPtrs<T, NL_NUM_OUT> co;
-    for (int i = 0; i < NL_NUM_IN; ++i) ci.p[i] = in[i];
+    for (int i = 0; i < NL_NUM_IN; ++i) {
+        ci.p[i] = in[i];
+        cii.p[i] = in_i ? in_i[i] : nullptr;
+    }
     for (int i = 0; i < NL_NUM_OUT; ++i) co.p[i] = out[i];
     const dim3 grid((nx + kColBlock - 1) / kColBlock), block(kColBlock);
     const size_t smem = 2 * size_t(nz + 1) * sizeof(T);
     const bool evap = p.LEVAPLS2 || p.LDRAIN1D;
     const bool lin = p.LPHYLIN || p.LDRAIN1D;
     const T tdt = static_cast<T>(dt);
+    const T tpf = static_cast<T>(pf);
     const NLK<T> kc = make_nlk<T>(p, dt, evap);
     const ExpK<T> xk = make_expk<T>();
     if (!fits_u32_offsets<T>(nz, ls)) return -2;
-#define CS2_NL_LAUNCH(EV, LN) \
-    hipLaunchKernelGGL((nl_kernel<T, EV, LN, sizeof(T) == 8>), grid, block, smem, stream, e, kc, xk, nx, nz, ls, ci, eta, co, tdt)
-    if (evap && lin) CS2_NL_LAUNCH(true, true);
-    else if (evap && !lin) CS2_NL_LAUNCH(true, false);
-    else if (!evap && lin) CS2_NL_LAUNCH(false, true);
-    else CS2_NL_LAUNCH(false, false);
+    const int fuse = qsat_out ? 1 : (in_i ? 2 : 0);
+    if (fuse == 1 && !p.LPHYLIN) return -2;   // only the LPHYLIN form of `saturation` is fused
+#define CS2_NL_LAUNCH(EV, LN, FU)                                                                                 \
+    hipLaunchKernelGGL((nl_kernel<T, EV, LN, sizeof(T) == 8, FU>), grid, block, smem, stream, e, kc, xk, nx, nz, \
+                       ls, ci, eta, co, tdt, cii, tpf, qsat_out)
+#define CS2_NL_FLAGS(FU)                                   \
+    do {                                                   \
+        if (evap && lin) CS2_NL_LAUNCH(true, true, FU);    \
+        else if (evap && !lin) CS2_NL_LAUNCH(true, false, FU); \
+        else if (!evap && lin) CS2_NL_LAUNCH(false, true, FU); \
+        else CS2_NL_LAUNCH(false, false, FU);              \
+    } while (0)
+    if (fuse == 0) CS2_NL_FLAGS(0);
+    else if (fuse == 1) CS2_NL_FLAGS(1);
+    else CS2_NL_FLAGS(2);
+#undef CS2_NL_FLAGS
 #undef CS2_NL_LAUNCH
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 template int launch_nl<double>(const Cloudsc2Params&, int, int, int64_t, const double* const*, const double*,
-                               double* const*, double, hipStream_t);
+                               double* const*, double, hipStream_t, const double* const*, double, double*);
 template int launch_nl<float>(const Cloudsc2Params&, int, int, int64_t, const float* const*, const float*,
-                              float* const*, double, hipStream_t);
+                              float* const*, double, hipStream_t, const float* const*, double, float*);
 
 }  // namespace cs2

@@ -15,7 +15,8 @@ def core(args):
     tt = TaylorTest(ctx["grid"], factor1=0.01, factor2s=tuple(10 ** -(i + 1) for i in range(10)), kflag=1,
                     lphylin=True, ldrain1d=False, yoethf_params=p["yoethf"], yomcst_params=p["yomcst"],
                     yrecldp_params=p["yrecldp"], yrephli_params=p["yrephli"], yrncl_params=p["yrncl"],
-                    yrphnc_params=p["yrphnc"], enable_checks=cfg.sympl_enable_checks, gt4py_config=cfg.gt4py_config)
+                    yrphnc_params=p["yrphnc"], enable_checks=cfg.sympl_enable_checks, gt4py_config=cfg.gt4py_config,
+                    fused=args.fused)
     norms = tt.run(ctx["state"], ctx["dt"])                  # warm-up; these norms are the validated ones
     runtimes = []
     for _ in range(cfg.num_runs):
@@ -33,6 +34,8 @@ def core(args):
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__)
     add_common_options(ap)
+    ap.add_argument("--fused", action="store_true",
+                    help="apply the perturbation inside the NL kernel (build extension cloudsc2_nl_perturbed)")
     args = ap.parse_args(argv)
     init_distributed_from_env()
     return core(args)

@@ -21,7 +21,8 @@ import torch
 
 from . import storage
 from .framework.timing import timing
-from .physics import Cloudsc2AD, Cloudsc2NL, Cloudsc2TL, PerturbedState, Saturation, StateIncrement
+from .physics import (Cloudsc2AD, Cloudsc2NL, Cloudsc2NLPerturbed, Cloudsc2TL, PerturbedState, Saturation,
+                      StateIncrement)
 
 _TENDS = ("f_t", "f_q", "f_ql", "f_qi")
 _DIAGS = ("f_clc", "f_fhpsl", "f_fhpsn", "f_fplsl", "f_fplsn", "f_covptot")
@@ -65,8 +66,9 @@ def taylor_verdict(norms: Sequence[float]) -> Tuple[bool, str]:
 class TaylorTest:
     def __init__(self, computational_grid, factor1: float, factor2s: Tuple[float, ...], kflag: int, lphylin: bool,
                  ldrain1d: bool, yoethf_params, yomcst_params, yrecldp_params, yrephli_params, yrncl_params,
-                 yrphnc_params, *, enable_checks: bool = True, gt4py_config) -> None:
+                 yrphnc_params, *, enable_checks: bool = True, gt4py_config, fused: bool = False) -> None:
         self.f1, self.f2s = factor1, tuple(factor2s)
+        self.fused = fused
         # no regularization in the Taylor test (validation.py:84-85)
         yrncl = dict(yrncl_params.dict() if hasattr(yrncl_params, "dict") else yrncl_params)
         yrncl["LREGCL"] = False
@@ -77,7 +79,14 @@ class TaylorTest:
         self.cloudsc2_tl = Cloudsc2TL(computational_grid, lphylin, ldrain1d, yoethf_params, yomcst_params,
                                       yrecldp_params, yrephli_params, yrncl, yrphnc_params, **kw)
         self.state_increment = StateIncrement(computational_grid, factor1, **kw)
-        self.perturbed_states = [PerturbedState(computational_grid, f2, **kw) for f2 in self.f2s]
+        if fused:
+            # build extension: perturbation applied inside the NL kernel's loads (no perturbed copy of the state)
+            self.perturbed_nls = [Cloudsc2NLPerturbed(computational_grid, f2, lphylin, ldrain1d, yoethf_params,
+                                                      yomcst_params, yrecldp_params, yrephli_params, yrphnc_params,
+                                                      **kw) for f2 in self.f2s]
+            self.perturbed_states = [None] * len(self.f2s)
+        else:
+            self.perturbed_states = [PerturbedState(computational_grid, f2, **kw) for f2 in self.f2s]
         self.diags_sat: Dict[str, Any] = {}
         self.state_i: Dict[str, Any] = {}
         self.state_p: Dict[str, Any] = {}
@@ -109,11 +118,15 @@ class TaylorTest:
         norms = np.zeros(len(self.f2s))
         for i, perturbed_state in enumerate(self.perturbed_states):
             with timing("run"):
-                self.state_p = perturbed_state(state, out=self.state_p)
-                self.state_p["time"] = state.get("time")
-                self.state_p["f_eta"] = state["f_eta"]
-                self.tends_nl_p, self.diags_nl_p = self.cloudsc2_nl(
-                    self.state_p, timestep, out_tendencies=self.tends_nl_p, out_diagnostics=self.diags_nl_p)
+                if self.fused:
+                    self.tends_nl_p, self.diags_nl_p = self.perturbed_nls[i](
+                        state, timestep, out_tendencies=self.tends_nl_p, out_diagnostics=self.diags_nl_p)
+                else:
+                    self.state_p = perturbed_state(state, out=self.state_p)
+                    self.state_p["time"] = state.get("time")
+                    self.state_p["f_eta"] = state["f_eta"]
+                    self.tends_nl_p, self.diags_nl_p = self.cloudsc2_nl(
+                        self.state_p, timestep, out_tendencies=self.tends_nl_p, out_diagnostics=self.diags_nl_p)
             with timing("norms"):
                 diffs = torch.stack([_sum64(getattr(self, k + "_nl_p")[n].data - getattr(self, k + "_nl")[n].data)
                                      for k, n in names])

@@ -188,6 +188,76 @@ class Cloudsc2NL(ImplicitTendencyComponent):
                       domain=(g.nx, 1, g.nz + 1), **_stencil_common(self))
 
 
+class Cloudsc2NLSaturation(Cloudsc2NL):
+    """BUILD EXTENSION: `Saturation` + `Cloudsc2NL` as ONE kernel launch (stencil `cloudsc2_nl_saturation`).
+    Same inputs as `Cloudsc2NL` minus `f_qsat`, which becomes an additional diagnostic output; the result is
+    bit-identical to calling the two components in sequence (tests/test_hip_nl.py)."""
+
+    def __init__(self, computational_grid, lphylin: bool, ldrain1d: bool, yoethf_params, yomcst_params,
+                 yrecldp_params, yrephli_params, yrphnc_params, *, enable_checks: bool = True, gt4py_config) -> None:
+        ImplicitTendencyComponent.__init__(self, computational_grid, enable_checks=enable_checks,
+                                           gt4py_config=gt4py_config)
+        ext = _externals(yoethf_params, yomcst_params, yrecldp_params, yrephli_params, yrphnc_params,
+                         ICALL=0, LPHYLIN=lphylin, LDRAIN1D=ldrain1d, ZEPS1=1e-12, ZEPS2=1e-10, ZQMAX=0.5, ZSCAL=0.9,
+                         KFLAG=1, QMAX=0.5)
+        self.cloudsc2 = self.compile_stencil("cloudsc2_nl_saturation", ext)
+
+    @cached_property
+    def input_grid_properties(self):
+        props = {"f_" + n: _prop(n) for n in NL_IN if n != "qsat"}
+        props["f_eta"] = {"grid_dims": (K,), "units": ""}
+        return props
+
+    @cached_property
+    def diagnostic_grid_properties(self):
+        props = {"f_" + n: _prop(n) for n in _DIAG_OUT}
+        props["f_qsat"] = _prop("qsat")
+        return props
+
+    def array_call(self, state, timestep: timedelta, out_tendencies, out_diagnostics, overwrite_tendencies) -> None:
+        g = self.computational_grid
+        kw = {"in_" + n: state["f_" + n] for n in NL_IN if n != "qsat"}
+        kw["out_qsat"] = out_diagnostics["f_qsat"]
+        kw.update({"out_" + n: out_diagnostics["f_" + n] for n in _DIAG_OUT})
+        kw.update({"out_" + n: out_tendencies[_tend_name(n)] for n in _TEND_OUT})
+        self.cloudsc2(**kw, in_eta=state["f_eta"], dt=self.gt4py_config.dtypes.float(timestep.total_seconds()),
+                      domain=(g.nx, 1, g.nz + 1), **_stencil_common(self))
+
+
+class Cloudsc2NLPerturbed(Cloudsc2NL):
+    """BUILD EXTENSION: `PerturbedState(factor)` + `Cloudsc2NL` as ONE kernel launch (stencil
+    `cloudsc2_nl_perturbed`): the state fields are read as x + factor * x_i on the fly."""
+
+    def __init__(self, computational_grid, factor: float, lphylin: bool, ldrain1d: bool, yoethf_params, yomcst_params,
+                 yrecldp_params, yrephli_params, yrphnc_params, *, enable_checks: bool = True, gt4py_config) -> None:
+        ImplicitTendencyComponent.__init__(self, computational_grid, enable_checks=enable_checks,
+                                           gt4py_config=gt4py_config)
+        self.f = gt4py_config.dtypes.float(factor)
+        ext = _externals(yoethf_params, yomcst_params, yrecldp_params, yrephli_params, yrphnc_params,
+                         ICALL=0, LPHYLIN=lphylin, LDRAIN1D=ldrain1d, ZEPS1=1e-12, ZEPS2=1e-10, ZQMAX=0.5, ZSCAL=0.9)
+        self.cloudsc2 = self.compile_stencil("cloudsc2_nl_perturbed", ext)
+
+    @cached_property
+    def input_grid_properties(self):
+        props = {"f_eta": {"grid_dims": (K,), "units": ""}}
+        for n in NL_IN:
+            props["f_" + n] = _prop(n)
+            props["f_" + n + "_i"] = _prop(n)
+        return props
+
+    def array_call(self, state, timestep: timedelta, out_tendencies, out_diagnostics, overwrite_tendencies) -> None:
+        g = self.computational_grid
+        kw = {}
+        for n in NL_IN:
+            kw["in_" + n] = state["f_" + n]
+            kw["in_" + n + "_i"] = state["f_" + n + "_i"]
+        kw.update({"out_" + n: out_diagnostics["f_" + n] for n in _DIAG_OUT})
+        kw.update({"out_" + n: out_tendencies[_tend_name(n)] for n in _TEND_OUT})
+        self.cloudsc2(**kw, in_eta=state["f_eta"], f=self.f,
+                      dt=self.gt4py_config.dtypes.float(timestep.total_seconds()),
+                      domain=(g.nx, 1, g.nz + 1), **_stencil_common(self))
+
+
 class Cloudsc2TL(ImplicitTendencyComponent):
     def __init__(self, computational_grid, lphylin: bool, ldrain1d: bool, yoethf_params, yomcst_params,
                  yrecldp_params, yrephli_params, yrncl_params, yrphnc_params, *, enable_checks: bool = True,

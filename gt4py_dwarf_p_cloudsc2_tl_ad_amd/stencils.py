@@ -165,6 +165,50 @@ class Cloudsc2NLStencil(HipStencil):
             _ptrs(fields, ["out_" + n for n in NL_OUT]), scalar, stream)
 
 
+class Cloudsc2NLSaturationStencil(HipStencil):
+    """BUILD EXTENSION `cloudsc2_nl_saturation`: `saturation` + `cloudsc2_nl` in one launch (C ABI
+    `cloudsc2_nl_fused_*` with `qsat_out`).  Arguments of `cloudsc2_nl` minus `in_qsat`, plus `out_qsat`."""
+
+    name = "cloudsc2_nl_saturation"
+
+    def _field_names(self):
+        return (tuple("in_" + n for n in NL_IN if n != "qsat") + ("out_qsat",)
+                + tuple("out_" + n for n in NL_OUT))
+
+    def _launch(self, fields, eta, scalar, nx, nz, ls, sfx, stream):
+        if eta is None:
+            raise TypeError(f"{self.name}: missing field argument 'in_eta'")
+        ins = _lib.ptr_array([0 if n == "qsat" else fields["in_" + n].data_ptr() for n in NL_IN])
+        return self._fn("nl_fused", sfx)(
+            ctypes.byref(self.params), nx, nz, ls, ins, None, 0.0, fields["out_qsat"].data_ptr(), eta.data_ptr(),
+            _ptrs(fields, ["out_" + n for n in NL_OUT]), scalar, stream)
+
+
+class Cloudsc2NLPerturbedStencil(HipStencil):
+    """BUILD EXTENSION `cloudsc2_nl_perturbed`: `perturbed_state` + `cloudsc2_nl` in one launch: the inputs are
+    read as in_X + f * in_X_i.  Arguments of `cloudsc2_nl` plus the 16 `in_*_i` fields and the scalar `f`."""
+
+    name = "cloudsc2_nl_perturbed"
+
+    def __call__(self, **kwargs: Any) -> None:
+        if "f" not in kwargs:
+            raise TypeError(f"{self.name}: missing scalar argument 'f'")
+        self._pf = float(kwargs.pop("f"))
+        super().__call__(**kwargs)
+
+    def _field_names(self):
+        return (tuple("in_" + n for n in NL_IN) + tuple("in_" + n + "_i" for n in NL_IN)
+                + tuple("out_" + n for n in NL_OUT))
+
+    def _launch(self, fields, eta, scalar, nx, nz, ls, sfx, stream):
+        if eta is None:
+            raise TypeError(f"{self.name}: missing field argument 'in_eta'")
+        return self._fn("nl_fused", sfx)(
+            ctypes.byref(self.params), nx, nz, ls, _ptrs(fields, ["in_" + n for n in NL_IN]),
+            _ptrs(fields, ["in_" + n + "_i" for n in NL_IN]), self._pf, None, eta.data_ptr(),
+            _ptrs(fields, ["out_" + n for n in NL_OUT]), scalar, stream)
+
+
 class Cloudsc2TLStencil(HipStencil):
     """`cloudsc2_tl` - tangent_linear/_stencils/cloudsc2.py:23-90 (signature), :124-774 (body)."""
 
@@ -259,6 +303,8 @@ class PerturbedStateStencil(HipStencil):
 #: registry keyed by the names the reference registers with `@stencil_collection(name)`
 STENCILS: Dict[str, type] = {
     "cloudsc2_nl": Cloudsc2NLStencil,
+    "cloudsc2_nl_saturation": Cloudsc2NLSaturationStencil,   # build extension (fused)
+    "cloudsc2_nl_perturbed": Cloudsc2NLPerturbedStencil,     # build extension (fused)
     "cloudsc2_tl": Cloudsc2TLStencil,
     "cloudsc2_ad": Cloudsc2ADStencil,
     "saturation": SaturationStencil,

@@ -83,6 +83,20 @@ int32_t cloudsc2_nl_f32(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t
                         const float* const* in, const float* eta, float* const* out, double dt,
                         void* stream);
 
+/* ---- cloudsc2_nl, fused variants (BUILD EXTENSIONS - the reference has no such stencil).
+ * Exactly one of `qsat_out` / `in_i` is non-NULL; results are those of the separate stencil calls.
+ *   qsat_out != NULL : `saturation` (LPHYLIN form, common/_stencils/saturation.py:30-35,42) is evaluated inside the
+ *                      NL kernel from in[NL_IN_AP], in[NL_IN_T]; in[NL_IN_QSAT] is not read (may be NULL) and the
+ *                      result is written to qsat_out: the driver's timed region (run_nonlinear.py:117-118) in ONE launch.
+ *   in_i != NULL     : every input is read as in[f] + pf * in_i[f] (perturbed_state, perturbed_state.py:75-91): the
+ *                      Taylor test's perturbed NL runs (tangent_linear/validation.py:166-176) without the perturbed copy. */
+int32_t cloudsc2_nl_fused_f64(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t lev_stride,
+                              const double* const* in, const double* const* in_i, double pf, double* qsat_out,
+                              const double* eta, double* const* out, double dt, void* stream);
+int32_t cloudsc2_nl_fused_f32(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t lev_stride,
+                              const float* const* in, const float* const* in_i, double pf, float* qsat_out,
+                              const float* eta, float* const* out, double dt, void* stream);
+
 /* ---- saturation : common/_stencils/saturation.py:23-42, called at common/saturation.py:67-76
  * (domain nx x 1 x nz: level nz of out_qsat is not written) */
 int32_t cloudsc2_saturation_f64(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t lev_stride,

@@ -169,3 +169,21 @@ def test_exec_info_and_stencil_csv_on_hip(gpu, tmp_path, capsys):
     rows = [r.split(",") for r in text.strip().splitlines()[1:]]
     for r in rows:
         assert int(r[7]) == 3 and 0.0 < float(r[8]) < 50.0          # 3 timed calls each, a sane mean in ms
+
+
+@pytest.mark.gpu
+def test_fused_driver_variants_match_the_unfused_ones(gpu, capsys):
+    """`--fused` (saturation inside NL; perturbation inside NL) are build extensions: same results, fewer launches."""
+    import torch
+
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.drivers import run_nonlinear, run_taylor_test
+
+    a = run_nonlinear.main(["--backend", "hip", "--num-cols", "4096", "--num-runs", "2", "--disable-validation"])
+    b = run_nonlinear.main(["--backend", "hip", "--num-cols", "4096", "--num-runs", "2", "--disable-validation", "--fused"])
+    for d in ("tends", "diags"):
+        for k, v in a[d].items():
+            assert torch.equal(v.data, b[d][k].data), k
+    t0 = run_taylor_test.main(["--backend", "hip", "--num-cols", "4096", "--disable-validation"])
+    t1 = run_taylor_test.main(["--backend", "hip", "--num-cols", "4096", "--disable-validation", "--fused"])
+    np.testing.assert_allclose(t1["norms"], t0["norms"], rtol=1e-12)
+    capsys.readouterr()

@@ -17,7 +17,7 @@ for the barrier / max-over-ranks timing and for the final validation-norm all-re
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (`nl_kernel`): algorithmic bytes
 per launch (28 536 B/column fp64) / the kernel's mean duration measured with HIP
-events on the launch stream.  `cpu_baseline` times the NumPy oracle (1 core) on a bounded sample.
+events on the launch stream.  `cpu_baseline` times the C/OpenMP and NumPy restatements on a bounded sample.
 """
 from __future__ import annotations
 
@@ -49,36 +49,60 @@ def parse_args():
     return ap.parse_args()
 
 
-def cpu_baseline(cols: int, nz: int, np_dtype, budget_s: float = 12.0):
-    """Oracle (NumPy restatement, the GT4Py-numpy-like execution shape) on the host: saturation + NL
-    on `cols` synthetic columns, repeated until ~`budget_s` seconds of CPU work have been timed."""
+def cpu_baseline(cols: int, nz: int, np_dtype, budget_s: float = 8.0):
+    """CPU baselines on the host, saturation + cloudsc2_nl on `cols` synthetic columns (BASELINE configs[0] size):
+      * headline `value`: the plain-C + OpenMP restatement (oracle/cloudsc2_nl_omp.c, SURVEY 8d "restatement B")
+        on the host cores of this GPU's share, fp64, repeated for ~`budget_s` s;
+      * `numpy_1core`: the NumPy restatement (GT4Py-numpy-like execution shape, single-threaded) for ~6 s.
+    Both are the checker (pinned to the executed reference source by tests/), timed here only as baselines."""
     import numpy as np
 
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from helpers import externals, nl_case, run_oracle_nl
+    from helpers import NL_OUT, externals, nl_case, run_oracle_nl
+    from oracle import cloudsc2_c
     from oracle import cloudsc2_numpy as oracle
 
     ext = externals()
     run_oracle_nl(*nl_case(64, nz, np_dtype), ext)  # warm-up (imports, allocator)
     fields, eta, dt = nl_case(cols, nz, np_dtype)
-    runs, t0 = 0, time.perf_counter()
-    while True:
+
+    def loop(step, budget):
+        step()
+        runs, t0 = 0, time.perf_counter()
+        while True:
+            step()
+            runs += 1
+            el = time.perf_counter() - t0
+            if el >= budget or runs >= 500:
+                return runs, el
+
+    def numpy_step():
         oracle.saturation(fields["in_ap"], fields["in_t"], fields["in_qsat"], ext)
         run_oracle_nl(fields, eta, dt, ext)
-        runs += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s or runs >= 200:
-            break
-    return {
-        "value": cols * runs / el,
-        "unit": "columns/s",
-        "cores": 1,
-        "host_cores": os.cpu_count(),
-        "kind": "port",
-        "sample": f"NumPy oracle (oracle/cloudsc2_numpy.py; GT4Py-numpy-like execution shape, single-threaded), "
-                  f"saturation + cloudsc2_nl, {cols} cols x {nz} lev {np.dtype(np_dtype).name} "
-                  f"(BASELINE configs[0] size), {runs} runs in {el:.1f} s, synthetic-parameters",
-    }
+
+    n_runs, n_el = loop(numpy_step, 6.0)
+    numpy_rate = cols * n_runs / n_el
+    what = f"saturation + cloudsc2_nl, {cols} cols x {nz} lev"
+    res = {"unit": "columns/s", "host_cores": os.cpu_count(), "kind": "port",
+           "numpy_1core": {"value": numpy_rate, "unit": "columns/s", "cores": 1,
+                           "sample": f"NumPy restatement, {what} {np.dtype(np_dtype).name}, {n_runs} runs in {n_el:.1f} s"}}
+    try:
+        threads = min(len(os.sched_getaffinity(0)), 16)
+        F = {k: np.ascontiguousarray(v, dtype=np.float64) for k, v in fields.items()}
+        for n in NL_OUT:
+            F["out_" + n] = np.zeros_like(F["in_ap"])
+
+        def c_step():
+            cloudsc2_c.saturation(F["in_ap"], F["in_t"], F["in_qsat"], ext, nthreads=threads)
+            cloudsc2_c.cloudsc2_nl(F, eta, dt, ext, nthreads=threads)
+
+        c_runs, c_el = loop(c_step, budget_s)
+        res.update(value=cols * c_runs / c_el, cores=threads,
+                   sample=f"plain-C + OpenMP restatement (oracle/cloudsc2_nl_omp.c, {threads} threads, scalar libm), "
+                          f"{what} float64, {c_runs} runs in {c_el:.1f} s, synthetic-parameters")
+    except Exception as exc:  # the C library is optional test infrastructure: fall back to the NumPy figure
+        res.update(value=numpy_rate, cores=1, sample=res["numpy_1core"]["sample"] + f" (C restatement unavailable: {exc})")
+    return res
 
 
 class _StdoutToStderr:

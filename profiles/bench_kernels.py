@@ -9,7 +9,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 WORDS = {"saturation": 411, "state_increment": 4416, "perturbed_state": 6624, "cloudsc2_nl": 3567,
-         "cloudsc2_tl": 7134, "cloudsc2_ad": 7134}
+         "cloudsc2_tl": 7134, "cloudsc2_ad": 7134,
+         # sequences and the fused build extensions that replace them (words = those of the FUSED form)
+         "saturation+nl": 3567, "nl_saturation(fused)": 3567,               # 15 in + qsat out + 10 out
+         "perturbed+nl": 5759, "nl_perturbed(fused)": 5759}                 # 2 x 16 in + 10 out
 
 
 def main():
@@ -49,6 +52,18 @@ def main():
     nl_out = {"out_" + n: Z() for n in NL_OUT}
     nl = compile_stencil("cloudsc2_nl", ext)
     calls["cloudsc2_nl"] = lambda: nl(**f, **nl_out, in_eta=eta, dt=3600.0, domain=(nx, 1, nz + 1), **com)
+    calls["saturation+nl"] = lambda: (calls["saturation"](), calls["cloudsc2_nl"]())
+    nls = compile_stencil("cloudsc2_nl_saturation", ext)
+    f_noq = {k: v for k, v in f.items() if k != "in_qsat"}
+    calls["nl_saturation(fused)"] = lambda: nls(**f_noq, out_qsat=f["in_qsat"], **nl_out, in_eta=eta, dt=3600.0,
+                                                domain=(nx, 1, nz + 1), **com)
+    fp = {"in_" + n: per_out["out_" + n] for n in NL_IN}
+    calls["perturbed+nl"] = lambda: (calls["perturbed_state"](),
+                                     nl(**fp, **nl_out, in_eta=eta, dt=3600.0, domain=(nx, 1, nz + 1), **com))
+    nlp = compile_stencil("cloudsc2_nl_perturbed", ext)
+    fi_nl = {"in_" + n + "_i": inc_out["out_" + n + "_i"] for n in NL_IN}
+    calls["nl_perturbed(fused)"] = lambda: nlp(**f, **fi_nl, **nl_out, f=1e-3, in_eta=eta, dt=3600.0,
+                                               domain=(nx, 1, nz + 1), **com)
     tl_out = {"out_" + n: Z() for n in NL_OUT}
     tl_out.update({"out_" + n + "_i": Z() for n in NL_OUT})
     tl = compile_stencil("cloudsc2_tl", ext)

@@ -6,9 +6,9 @@
 // per column, carried state (rfl, sfl, covptot and their perturbations) in registers, level k+1
 // prefetched while level k is computed, flux shift fused into the sweep.
 //
-// Template flag REG = LREGCL (regularisations :294-301, :367-368, :444-448, :475-487, :667-668).
-// The precipitation-evaporation block (:528-616, LEVAPLS2 or LDRAIN1D) is not instantiated: the
-// launcher rejects those externals (the reference's own drivers never enable them).
+// Template flags: REG = LREGCL (regularisations :294-301, :367-368, :444-448, :475-487, :667-668);
+// EVAP = LEVAPLS2 or LDRAIN1D (precipitation-evaporation block :528-616 and the 1.9 RCLCRIT / 1e-4
+// autoconversion thresholds; never enabled by the reference's own drivers).
 #include "cloudsc2_common.hpp"
 
 namespace cs2 {
@@ -43,11 +43,13 @@ __device__ __forceinline__ TLIn<T> tl_load(const CPtrs<T, NL_NUM_IN>& in, uint32
 template <typename T>
 struct TLCarry {
     T rfl, rfl_i, sfl, sfl_i, covptot, covptot_i, aph_k, aph_k_i;
+    T aph_s, aph_s_i;  // surface pressure and its perturbation (:126-127), read by the evaporation block only
 };
 
 template <typename T>
 struct TLOut {
     T clc, clc_i, tnd_q, tnd_q_i, tnd_t, tnd_t_i, tnd_ql, tnd_ql_i, tnd_qi, tnd_qi_i, rfln, rfln_i, sfln, sfln_i;
+    T covptot, covptot_i;  // :185-186, non-zero only where the evaporation block ran (:586-587)
 };
 
 // One iteration of tangent_linear/_stencils/cuadjtqs.py:22-52 with shared reciprocals
@@ -85,7 +87,7 @@ __device__ __forceinline__ void tl_cuadj_iter(const Ext<T>& e, const ExpK<T>& xk
 // Same algebra as the reference; divisions are x * frcp(y) with shared reciprocals, tanh/cosh come
 // from ONE exponential: with ex = exp(-0.34 (t - RLPTRC)), rr = 1/(1 + ex):
 //   0.545 (tanh u + 1) = 1.09 rr,   1 / cosh(u)^2 = 4 ex rr^2      (u = 0.17 (t - RLPTRC)).
-template <typename T, bool REG>
+template <typename T, bool REG, bool EVAP>
 __device__ __forceinline__ TLOut<T> tl_level(const Ext<T>& e, const NLK<T>& kc, const ExpK<T>& xk, const TLIn<T>& x,
                                              const TLIn<T>& y, int k, T eta_k, T scalm, const CrhCol<T>& crh, T dt,
                                              TLCarry<T>& c) {
@@ -151,7 +153,7 @@ __device__ __forceinline__ TLOut<T> tl_level(const Ext<T>& e, const NLK<T>& kc, 
     const T cor_i = e.RETV * esdp_i * cor * cor;
     const T dqsdtemp = fac * cor * x.qsat;
     const T dqsdtemp_i = fac_i * cor * x.qsat + fac * cor_i * x.qsat + fac * cor * y.qsat;
-    // (:221-230 corqs / qlim feed only the evaporation block, which is not instantiated)
+    // (:221-230 corqs / qlim feed only the evaporation block and are formed there)
     // :233-253
     const T crh2 = crh2_at(crh, eta_k);
     // :256-265
@@ -339,12 +341,90 @@ __device__ __forceinline__ TLOut<T> tl_level(const Ext<T>& e, const NLK<T>& kc, 
         rfln += dr;
         rfln_i += dr_i;
     }
-    // :526-616 evaporation: not instantiated (evapr = evaps = 0)
-    // :619-659
-    const T hh = x.lude * ldcp;
-    const T hh_i = y.lude * ldcp + x.lude * ldcp_i;
-    const T dqdt = -(condl + condi) + x.lude * gdp;
-    const T dqdt_i = -(condl_i + condi_i) + y.lude * gdp + x.lude * gdp_i;
+    // :526-616 precipitation evaporation (LEVAPLS2 or LDRAIN1D).  q / q_i are still the first guess of :154-156
+    // here, so corqs (:221-222) and qlim (:225-230) are formed in place; covpclr is :392-397.
+    T evapr = T(0.0), evapr_i = T(0.0), evaps = T(0.0), evaps_i = T(0.0);
+    o.covptot = T(0.0);
+    o.covptot_i = T(0.0);
+    if constexpr (EVAP) {
+        T covpclr = c.covptot - clc;
+        T covpclr_i = c.covptot_i - clc_i;
+        if (covpclr < T(0.0)) {
+            covpclr = T(0.0);
+            covpclr_i = T(0.0);
+        }
+        const T prtot = rfln + sfln;
+        const T prtot_i = rfln_i + sfln_i;
+        if (prtot > e.ZEPS2 && covpclr > e.ZEPS2) {
+            const T corqs = T(1.0) + kc.cons3 * dqsdtemp;
+            const T corqs_i = kc.cons3 * dqsdtemp_i;
+            T qlim, qlim_i;
+            if (q > x.qsat) {
+                qlim = x.qsat;
+                qlim_i = y.qsat;
+            } else {
+                qlim = q;
+                qlim_i = q_i;
+            }
+            // trajectory quantities with discrete consequences (the covptot reset below, a flux that must become
+            // exactly 0 when everything evaporates) use IEEE division like the reference, not x * frcp(y)
+            const T rcov = frcp<T>(c.covptot);
+            const T preclr = prtot * covpclr / c.covptot;
+            const T preclr_i = (prtot_i * covpclr + prtot * covpclr_i) * rcov - prtot * covpclr * c.covptot_i * rcov * rcov;
+            const T romc = frcp<T>(T(1.0) - clc);
+            const T qe = x.qsat - (x.qsat - qlim) * covpclr * romc * romc;
+            const T qe_i = y.qsat - (y.qsat * covpclr - qlim_i * covpclr + (x.qsat - qlim) * covpclr_i) * romc * romc -
+                           T(2.0) * (x.qsat - qlim) * covpclr * clc_i * romc * romc * romc;
+            const T tmp6 = rsqrt_<T>(x.ap * frcp<T>(c.aph_s));
+            const T rcp = frcp<T>(covpclr);
+            const T arg = tmp6 * preclr * rcp * T(1.0 / 0.00509);
+            const T pw = rpow<T>(arg, T(0.5777));
+            const T beta = e.RG * e.RPECONS * pw;
+            // (0.00509 covpclr / (tmp6 preclr))^0.4223 = arg^-0.4223 = pw / arg
+            const T beta_i = T(0.5777 / 0.00509) * e.RG * e.RPECONS * pw * frcp<T>(arg) *
+                             ((tmp6 * preclr_i + T(0.5) * preclr * y.ap * frcp<T>(tmp6) -
+                               T(0.5) * preclr * tmp6 * c.aph_s_i * frcp<T>(c.aph_s)) * rcp -
+                              tmp6 * preclr * covpclr_i * rcp * rcp);
+            const T rden = frcp<T>(T(1.0) + dt * beta * corqs);
+            const T b = dt * beta * (x.qsat - qe) * rden;
+            // the reference's dt**2 factor in the second term is kept (tangent_linear/_stencils/cloudsc2.py:565-569)
+            const T b_i = dt * (beta_i * (x.qsat - qe) + beta * (y.qsat - qe_i)) * rden -
+                          dt * dt * b * (beta_i * corqs + beta * corqs_i) * rden;
+            const T rdtgdp = dp * frcp<T>(kc.rgdt);  // 1 / dtgdp = dp / (dt RG)
+            const T dtgdp_i = -dt * e.RG * dp_i * rdp * rdp;
+            T dpr = covpclr * b * rdtgdp;
+            T dpr_i = (covpclr_i * b + covpclr * b_i) * rdtgdp - covpclr * b * dtgdp_i * rdtgdp * rdtgdp;
+            // preclr - dpr <= 0 (:580) <=> dpr >= preclr; written as a comparison because `preclr - dpr` may be
+            // contracted into an fma with the product that defines preclr, which would leave a rounding residue
+            const bool all_evaporates = dpr >= preclr;
+            if (dpr > preclr) {
+                dpr = preclr;
+                dpr_i = preclr_i;
+            }
+            if (all_evaporates) {
+                c.covptot = clc;
+                c.covptot_i = clc_i;
+            }
+            o.covptot = c.covptot;
+            o.covptot_i = c.covptot_i;
+            const T rpr = frcp<T>(prtot);
+            evapr = dpr * rfln / prtot;
+            evapr_i = (dpr_i * rfln + dpr * rfln_i) * rpr - dpr * rfln * prtot_i * rpr * rpr;
+            rfln -= evapr;
+            rfln_i -= evapr_i;
+            evaps = dpr * sfln / prtot;
+            evaps_i = (dpr_i * sfln + dpr * sfln_i) * rpr - dpr * sfln * prtot_i * rpr * rpr;
+            sfln -= evaps;
+            sfln_i -= evaps_i;
+        }
+    }
+    // :619-659   (src = in_lude + evapr + evaps;  hh = the latent-heat weighted sum of the same three sources)
+    const T src = x.lude + evapr + evaps;
+    const T src_i = y.lude + evapr_i + evaps_i;
+    const T hh = x.lude * ldcp + lvdcp * evapr + lsdcp * evaps;
+    const T hh_i = y.lude * ldcp + x.lude * ldcp_i + lvdcp_i * evapr + lvdcp * evapr_i + lsdcp_i * evaps + lsdcp * evaps_i;
+    const T dqdt = -(condl + condi) + src * gdp;
+    const T dqdt_i = -(condl_i + condi_i) + src_i * gdp + src * gdp_i;
     const T tmp7 = hh - (lsdcp - lvdcp) * rfreeze;
     const T dtdt = lvdcp * condl + lsdcp * condi - tmp7 * gdp;
     const T dtdt_i = lvdcp_i * condl + lvdcp * condl_i + lsdcp_i * condi + lsdcp * condi_i -
@@ -395,8 +475,8 @@ __device__ __forceinline__ TLOut<T> tl_level(const Ext<T>& e, const NLK<T>& kc, 
     // :706-741
     o.clc = clc;
     o.clc_i = clc_i;
-    o.tnd_q = -(condl + condi) + x.lude * gdp;
-    o.tnd_q_i = -(condl_i + condi_i) + y.lude * gdp + x.lude * gdp_i;
+    o.tnd_q = -(condl + condi) + src * gdp;
+    o.tnd_q_i = -(condl_i + condi_i) + src_i * gdp + src * gdp_i;
     const T tmp8 = hh - (lsdcp - lvdcp) * rfreeze;
     o.tnd_t = lvdcp * condl + lsdcp * condi - tmp8 * gdp;
     o.tnd_t_i = lvdcp_i * condl + lvdcp * condl_i + lsdcp_i * condi + lsdcp * condi_i -
@@ -424,8 +504,8 @@ __device__ __forceinline__ void tl_store(const MPtrs<T, NL_NUM_OUT>& out, const 
                                          const Ext<T>& e, uint32_t lsb, uint32_t i, const TLOut<T>& o) {
     stg(out.p[NL_OUT_CLC], i, o.clc);
     stg(out_i.p[NL_OUT_CLC], i, o.clc_i);
-    stg(out.p[NL_OUT_COVPTOT], i, T(0.0));      // :185-186 (only the evaporation block sets it)
-    stg(out_i.p[NL_OUT_COVPTOT], i, T(0.0));
+    stg(out.p[NL_OUT_COVPTOT], i, o.covptot);   // :185-186 (only the evaporation block sets it non-zero)
+    stg(out_i.p[NL_OUT_COVPTOT], i, o.covptot_i);
     stg(out.p[NL_OUT_TND_Q], i, o.tnd_q);
     stg(out_i.p[NL_OUT_TND_Q], i, o.tnd_q_i);
     stg(out.p[NL_OUT_TND_T], i, o.tnd_t);
@@ -463,7 +543,7 @@ __device__ __forceinline__ T tl_trpaus(const T* __restrict__ pt, const T* __rest
     return trpaus;
 }
 
-template <typename T, bool REG>
+template <typename T, bool REG, bool EVAP>
 __global__ void __launch_bounds__(kColBlock)
 tl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, NL_NUM_IN> in,
           CPtrs<T, NL_NUM_IN> in_i, const T* __restrict__ eta, MPtrs<T, NL_NUM_OUT> out, MPtrs<T, NL_NUM_OUT> out_i,
@@ -498,6 +578,8 @@ tl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
     c.rfl = c.rfl_i = c.sfl = c.sfl_i = c.covptot = c.covptot_i = T(0.0);
     c.aph_k = ldg(in.p[NL_IN_APH], colb);
     c.aph_k_i = ldg(in_i.p[NL_IN_APH], colb);
+    c.aph_s = EVAP ? ldg(in.p[NL_IN_APH], uint32_t(nz) * lsb + colb) : T(1.0);
+    c.aph_s_i = EVAP ? ldg(in_i.p[NL_IN_APH], uint32_t(nz) * lsb + colb) : T(0.0);
 
     if (live) {
         // :757-765
@@ -519,7 +601,7 @@ tl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
             xn = tl_load<T>(in, lsb, o + lsb);
             yn = tl_load<T>(in_i, lsb, o + lsb);
         }
-        const TLOut<T> r = tl_level<T, REG>(e, kc, xk, xa, ya, k, s_eta[k], s_scalm[k], crh, dt, c);
+        const TLOut<T> r = tl_level<T, REG, EVAP>(e, kc, xk, xa, ya, k, s_eta[k], s_scalm[k], crh, dt, c);
         if (live) tl_store<T>(out, out_i, e, lsb, o, r);
         xa = xn;
         ya = yn;
@@ -530,7 +612,7 @@ tl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
 template <typename T>
 int launch_tl(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* const* in, const T* const* in_i,
               const T* eta, T* const* out, T* const* out_i, double dt, hipStream_t stream) {
-    if (p.LEVAPLS2 || p.LDRAIN1D) return -2;  // evaporation block not instantiated for TL
+    const bool evap = p.LEVAPLS2 || p.LDRAIN1D;
     const Ext<T> e = make_ext<T>(p);
     CPtrs<T, NL_NUM_IN> ci, cii;
     MPtrs<T, NL_NUM_OUT> co, coi;
@@ -539,15 +621,18 @@ int launch_tl(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
     const dim3 grid((nx + kColBlock - 1) / kColBlock), block(kColBlock);
     const size_t smem = 2 * size_t(nz + 1) * sizeof(T);
     const T tdt = static_cast<T>(dt);
-    const NLK<T> kc = make_nlk<T>(p, dt, false);
+    const NLK<T> kc = make_nlk<T>(p, dt, evap);
     const ExpK<T> xk = make_expk<T>();
     if (!fits_u32_offsets<T>(nz, ls)) return -2;
-    if (p.LREGCL)
-        hipLaunchKernelGGL((tl_kernel<T, true>), grid, block, smem, stream, e, kc, xk, nx, nz, ls, ci, cii, eta, co,
-                           coi, tdt);
-    else
-        hipLaunchKernelGGL((tl_kernel<T, false>), grid, block, smem, stream, e, kc, xk, nx, nz, ls, ci, cii, eta, co,
-                           coi, tdt);
+#define CS2_TL_LAUNCH(REG, EVAP)                                                                                     \
+    hipLaunchKernelGGL((tl_kernel<T, REG, EVAP>), grid, block, smem, stream, e, kc, xk, nx, nz, ls, ci, cii, eta, co, \
+                       coi, tdt)
+    if (p.LREGCL) {
+        if (evap) CS2_TL_LAUNCH(true, true); else CS2_TL_LAUNCH(true, false);
+    } else {
+        if (evap) CS2_TL_LAUNCH(false, true); else CS2_TL_LAUNCH(false, false);
+    }
+#undef CS2_TL_LAUNCH
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -227,9 +227,60 @@ def test_increment_and_perturbed_state(gpu, dtype):
         np.testing.assert_allclose(got, want, rtol=4 * np.finfo(dtype).eps, atol=0)
 
 
-def test_tl_ad_reject_evaporation_switch(gpu):
-    """LEVAPLS2 / LDRAIN1D have no TL/AD instantiation: the call must raise, not compute something else."""
+def _assert_close_by_column(name, got, want, tol):
+    """|got - want| <= tol * max_k |want[k, col]|: every column is judged on its own scale (the evaporation block's
+    perturbations span 40 orders of magnitude between columns)."""
+    assert not np.isnan(got).any(), f"{name}: NaN"
+    scale = np.abs(want).max(axis=0, keepdims=True)
+    err = np.abs(got - want)
+    bad = err > tol * scale + np.finfo(np.float64).tiny
+    assert not bad.any(), (f"{name}: {int(bad.sum())} points, worst {np.nanmax(err / (scale + 1e-300)):.2e} "
+                           f"of the column scale (tol {tol:.0e})")
+
+
+@pytest.mark.parametrize("dt", [1.0, 60.0])
+@pytest.mark.parametrize("sw", [dict(LEVAPLS2=True, LREGCL=False), dict(LDRAIN1D=True, LREGCL=True)])
+def test_tl_evaporation_block_matches_oracle(gpu, sw, dt):
+    """LEVAPLS2 / LDRAIN1D: the precipitation-evaporation block of cloudsc2_tl (tangent_linear/_stencils/
+    cloudsc2.py:528-616).  Increments are NOT proportional to the state (a uniform 1 % scaling is nearly a symmetry of
+    the scheme: several perturbations then cancel to rounding noise) and dt is 1 s / 60 s: the reference's b_i carries a
+    dt**2 where the derivative has dt (:565-569), so at dt = 3600 s the recurrence amplifies rounding noise by ~3600 per
+    level and no two implementations agree on the perturbations (see the next test)."""
+    nx = 333
+    ext = externals(NLEV=137, **sw)
+    fields, eta, _ = nl_case(nx, ext=ext)
+    rng = np.random.default_rng(5)
+    fi = {k: v * rng.uniform(0.5, 1.5, size=v.shape) for k, v in increments(fields, 0.01).items()}
+    want, want_i = run_oracle_tl(fields, fi, eta, dt, ext)
+    got, got_i = run_hip_tl(fields, fi, eta, dt, ext, gpu, nx, 137)
+    assert np.abs(want["covptot"]).max() > 0 and np.abs(want_i["covptot"]).max() > 0   # the block is exercised
+    for n in NL_OUT:
+        k = nlev_of(n, 137)
+        _assert_close_by_column(f"tl-evap out_{n}", got[n][:k], want[n][:k], 1e-9)
+        _assert_close_by_column(f"tl-evap out_{n}_i", got_i[n][:k], want_i[n][:k], 1e-9)
+
+
+def test_tl_evaporation_block_at_the_driver_timestep(gpu):
+    """dt = 3600 s (the drivers' timestep): the trajectory half of cloudsc2_tl must still match, and it must equal the
+    NL kernel's result for the same switches; the perturbations only have to be finite and of the oracle's magnitude
+    (they reach 1e57: the dt**2 quirk above)."""
+    nx = 333
+    ext = externals(NLEV=137, LEVAPLS2=True, LREGCL=False)
+    fields, eta, dt = nl_case(nx, ext=ext)
+    fi = increments(fields, 0.01)
+    want, want_i = run_oracle_tl(fields, fi, eta, dt, ext)
+    got, got_i = run_hip_tl(fields, fi, eta, dt, ext, gpu, nx, 137)
+    for n in NL_OUT:
+        k = nlev_of(n, 137)
+        _assert_close_by_column(f"tl-evap traj out_{n}", got[n][:k], want[n][:k], 1e-9)
+        assert np.isfinite(got_i[n][:k]).all()
+        assert np.abs(got_i[n][:k] - want_i[n][:k]).max() <= 1e-9 * np.abs(want_i[n][:k]).max()
+
+
+def test_ad_rejects_evaporation_switch(gpu):
+    """LEVAPLS2 / LDRAIN1D have no AD instantiation: the call must raise, not compute something else."""
     ext = externals(NLEV=137, LEVAPLS2=True)
     fields, eta, dt = nl_case(64)
+    forcing = {n: np.zeros_like(fields["in_ap"]) for n in NL_OUT}
     with pytest.raises(ValueError, match="LEVAPLS2"):
-        run_hip_tl(fields, increments(fields), eta, dt, ext, gpu, 64, 137)
+        run_hip_ad(fields, forcing, eta, dt, ext, gpu, 64, 137)

@@ -23,7 +23,10 @@
 //       freezing test uses the pre-adjustment t3 (:427, :577) and the adjoint of rfreeze1 tests the
 //       post-adjustment t (:729).  FIX = true (Cloudsc2Params.AD_TRAJ_FIX, a build extension) uses
 //       the tests of the NL/TL stencils instead, which makes AD the exact transpose of TL.
-// Template flags: REG = LREGCL.  The evaporation block (:357-394, :635-709) is not instantiated.
+// Template flags: REG = LREGCL; EVAP = LEVAPLS2 or LDRAIN1D (evaporation block :357-394 / :635-709).
+// With EVAP the precipitation cover entering a level (tmp_covptotp, :458) is a second loop-carried
+// trajectory value that is NOT an output (out_covptot is 0 on levels without evaporation): sweep 1
+// parks it in level k of out_mfd_i, sweep 2 reads it back before it overwrites that element.
 #include "cloudsc2_common.hpp"
 
 namespace cs2 {
@@ -157,15 +160,19 @@ struct ADTraj {
     T rclc, cldl, ltmp1, ltmp2, prr, cldi, itmp11, itmp12, itmp2, prs;
     T rfreeze1, fwatr1, t3, qold, dq, dr2, fwatr2, condl2, condi2, rfreeze3;
     T t_post, q_post, rfln, sfln, tnd_q, tnd_t, tnd_ql, tnd_qi;
+    // evaporation block (EVAP only)
+    T covptot1, covpclr1, covpclr, covptot, out_covptot, prtot, rfln2, sfln2, corqs, qlim, preclr1, romc, qe, sq, xx,
+        beta, rtmp1, b, dpr, evapr, evaps;
+    bool ev, capped, all_evaporates;
     bool lo1, lo3, melt, cloudy, t3_cold, tpost_cold, t2_cold;
     int cls;  // 0 clear (qt <= qcrit), 1 overcast, 2 partial
     CuadjSav<T> adj;
 };
 
-template <typename T, bool FIX>
+template <typename T, bool FIX, bool EVAP>
 __device__ __forceinline__ void ad_forward(const Ext<T>& e, const NLK<T>& kc, const ExpK<T>& xk, const ADIn<T>& x,
                                            T aph_k, int k, T eta_k, T scalm, const CrhCol<T>& crh, T dt, T rfl, T sfl,
-                                           ADTraj<T>& r) {
+                                           T covptot_in, T aph_s, ADTraj<T>& r) {
     // :135-137, :153-157
     T t = x.t + dt * x.tt;
     r.t2 = t;
@@ -276,6 +283,11 @@ __device__ __forceinline__ void ad_forward(const Ext<T>& e, const NLK<T>& kc, co
     r.qiwc1 = r.qc3 * (T(1.0) - r.fwat);
     r.condl1 = (r.qlwc1 - r.ql) * kc.rdt;
     r.condi1 = (r.qiwc1 - r.qi) * kc.rdt;
+    // :284-290 maximum overlap
+    r.covptot1 = rmax<T>(covptot_in, r.out_clc);
+    r.covptot = r.covptot1;
+    r.covpclr1 = r.covptot1 - r.out_clc;
+    r.covpclr = rmax<T>(r.covpclr1, T(0.0));
     // :293-302 melting of incoming snow;  cons = cons2 dp / lfdcp = cons2 dp zz / RLMLT
     r.melt = sfl != T(0.0);
     T rfln, sfln;
@@ -331,9 +343,46 @@ __device__ __forceinline__ void ad_forward(const Ext<T>& e, const NLK<T>& kc, co
         r.fwatr1 = T(1.0);
         rfln += dr1;
     }
-    // :401-419 (evapr = evaps = 0)
-    const T hh = x.lude * r.ldcp;
-    const T dqdt = -(r.condl1 + r.condi1) + x.lude * r.gdp;
+    // :356-394 precipitation evaporation.  IEEE divisions where the result has discrete consequences (see cloudsc2_tl.hip)
+    r.evapr = T(0.0);
+    r.evaps = T(0.0);
+    r.out_covptot = T(0.0);
+    r.ev = false;
+    if constexpr (EVAP) {
+        r.prtot = rfln + sfln;
+        r.rfln2 = rfln;
+        r.sfln2 = sfln;
+        r.ev = r.prtot > e.ZEPS2 && r.covpclr > e.ZEPS2;
+        if (r.ev) {
+            r.corqs = T(1.0) + kc.cons3 * r.dqsdtemp;  // :199
+            r.qlim = rmin<T>(r.q2, x.qsat);             // :200
+            r.preclr1 = r.prtot * r.covpclr / r.covptot1;
+            r.romc = frcp<T>(T(1.0) - r.out_clc);
+            r.qe = x.qsat - (x.qsat - r.qlim) * r.covpclr * r.romc * r.romc;
+            r.sq = rsqrt_<T>(x.ap * frcp<T>(aph_s));
+            const T arg = r.sq * T(1.0 / 0.00509) * r.preclr1 * frcp<T>(r.covpclr);
+            const T pw = rpow<T>(arg, T(0.5777));
+            r.beta = e.RG * e.RPECONS * pw;
+            // 0.5777 (RG RPECONS / 0.00509) (0.00509 covpclr / (preclr1 sq))^0.4223, and x^-0.4223 = x^0.5777 / x
+            r.xx = T(0.5777 / 0.00509) * e.RG * e.RPECONS * pw * frcp<T>(arg);
+            r.rtmp1 = frcp<T>(T(1.0) + dt * r.beta * r.corqs);
+            r.b = dt * r.beta * (x.qsat - r.qe) * r.rtmp1;
+            const T dpr1 = r.covpclr * r.b * r.dp * frcp<T>(kc.rgdt);  // / dtgdp, dtgdp = dt RG / dp
+            r.capped = dpr1 > r.preclr1;
+            r.dpr = r.capped ? r.preclr1 : dpr1;
+            r.all_evaporates = dpr1 >= r.preclr1;  // preclr = preclr1 - dpr <= 0
+            if (r.all_evaporates) r.covptot = r.out_clc;
+            r.out_covptot = r.covptot;
+            r.evapr = r.dpr * r.rfln2 / r.prtot;
+            rfln -= r.evapr;
+            r.evaps = r.dpr * r.sfln2 / r.prtot;
+            sfln -= r.evaps;
+        }
+    }
+    // :401-419
+    const T hh = x.lude * r.ldcp + r.lvdcp * r.evapr + r.lsdcp * r.evaps;
+    const T src = x.lude + r.evapr + r.evaps;
+    const T dqdt = -(r.condl1 + r.condi1) + src * r.gdp;
     const T dtdt = r.lvdcp * r.condl1 + r.lsdcp * r.condi1 - (hh - (r.lsdcp - r.lvdcp) * r.rfreeze1) * r.gdp;
     r.t3 = t + dt * dtdt;
     q = r.q2 + dt * dqdt;
@@ -363,7 +412,7 @@ __device__ __forceinline__ void ad_forward(const Ext<T>& e, const NLK<T>& kc, co
     r.condi2 = r.condi1 + (T(1.0) - r.fwatr2) * r.dq * kc.rdt;
     r.rfreeze3 = r.rfreeze1 + rfreeze2;
     // :442-455
-    r.tnd_q = -(r.condl2 + r.condi2) + x.lude * r.gdp;
+    r.tnd_q = -(r.condl2 + r.condi2) + src * r.gdp;
     r.tnd_t = r.lvdcp * r.condl2 + r.lsdcp * r.condi2 - (hh - (r.lsdcp - r.lvdcp) * r.rfreeze3) * r.gdp;
     r.tnd_ql = (qlwc - r.ql) * kc.rdt;
     r.tnd_qi = (qiwc - r.qi) * kc.rdt;
@@ -376,9 +425,10 @@ template <typename T>
 struct ADForce {
     T clc, tnd_q, tnd_qi, tnd_ql, tnd_t, fplsl1, fplsn1;  // flux forcings at half level k+1, already
                                                           // combined with the enthalpy-flux ones (:481-484)
+    T covptot;                                            // read by the evaporation block only
 };
 
-template <typename T>
+template <typename T, bool EVAP>
 __device__ __forceinline__ ADForce<T> ad_load_force(const CPtrs<T, NL_NUM_OUT>& a, const Ext<T>& e, uint32_t lsb,
                                                     uint32_t o) {
     ADForce<T> f;
@@ -389,12 +439,14 @@ __device__ __forceinline__ ADForce<T> ad_load_force(const CPtrs<T, NL_NUM_OUT>& 
     f.tnd_t = ldg(a.p[NL_OUT_TND_T], o);
     f.fplsl1 = ldg(a.p[NL_OUT_FPLSL], o + lsb) - ldg(a.p[NL_OUT_FHPSL], o + lsb) * e.RLVTT;
     f.fplsn1 = ldg(a.p[NL_OUT_FPLSN], o + lsb) - ldg(a.p[NL_OUT_FHPSN], o + lsb) * e.RLSTT;
+    f.covptot = EVAP ? ldg(a.p[NL_OUT_COVPTOT], o) : T(0.0);
     return f;
 }
 
 template <typename T>
 struct ADBack {   // carried from level k+1 to level k in the backward sweep
     T tmp_rfln_i, tmp_sfln_i, rfl_i, sfl_i, daph_i, dp_i;
+    T aph_s, covptot_i, aph_s_i;  // EVAP only: surface pressure;: covptot_i of the level below (:653), accumulated tmp_aph_s_i (:686)
 };
 
 template <typename T>
@@ -404,7 +456,7 @@ struct ADOut {
 
 // Backward statements of one level (:494-967 + this level's share of :970-996).  Divisions use the
 // reciprocals saved with the trajectory.
-template <typename T, bool REG, bool FIX>
+template <typename T, bool REG, bool FIX, bool EVAP>
 __device__ __forceinline__ ADOut<T> ad_backward(const Ext<T>& e, const NLK<T>& kc, const ADIn<T>& x, int k, T scalm,
                                                 T dt, T sfl, const ADTraj<T>& r, const ADForce<T>& f, ADBack<T>& b) {
     ADOut<T> o;
@@ -420,15 +472,19 @@ __device__ __forceinline__ ADOut<T> ad_backward(const Ext<T>& e, const NLK<T>& k
     T qiwc_i = f.tnd_qi * rdt;
     T o_ql = -f.tnd_ql * rdt;
     T qlwc_i = f.tnd_ql * rdt;
-    // :514-533 (evapr = evaps = 0)
+    // :514-533
     const T tt = f.tnd_t;
     const T mix = r.ldcp;  // fwat * lvdcp + (1 - fwat) * lsdcp
-    const T hh = x.lude * mix;
+    const T evapr = EVAP ? r.evapr : T(0.0), evaps = EVAP ? r.evaps : T(0.0);
+    const T hh = x.lude * mix + lvdcp * evapr + lsdcp * evaps;
+    const T src = x.lude + evapr + evaps;
     T gdp_i = -tt * (hh - (lsdcp - lvdcp) * r.rfreeze3);
     T condl_i = tt * lvdcp;
     T condi_i = tt * lsdcp;
-    T lvdcp_i = tt * r.condl2;
-    T lsdcp_i = tt * r.condi2;
+    T evapr_i = -tt * lvdcp * gdp;
+    T evaps_i = -tt * lsdcp * gdp;
+    T lvdcp_i = tt * (r.condl2 - evapr * gdp);
+    T lsdcp_i = tt * (r.condi2 - evaps * gdp);
     T o_lude = -tt * gdp * mix;
     lvdcp_i -= tt * x.lude * gdp * fwat;
     lsdcp_i -= tt * x.lude * gdp * (T(1.0) - fwat);
@@ -438,8 +494,10 @@ __device__ __forceinline__ ADOut<T> ad_backward(const Ext<T>& e, const NLK<T>& k
     T rfreeze_i = tt * (lsdcp - lvdcp) * gdp;
     // :536-542
     const T tq = f.tnd_q;
-    gdp_i += tq * x.lude;
+    gdp_i += tq * src;
     o_lude += tq * gdp;
+    evapr_i += tq * gdp;
+    evaps_i += tq * gdp;
     condl_i -= tq;
     condi_i -= tq;
     // :566-592
@@ -470,8 +528,10 @@ __device__ __forceinline__ ADOut<T> ad_backward(const Ext<T>& e, const NLK<T>& k
     gdp_i -= dtdt_i * (hh - (lsdcp - lvdcp) * r.rfreeze1);
     condl_i += dtdt_i * lvdcp;
     condi_i += dtdt_i * lsdcp;
-    lvdcp_i += dtdt_i * r.condl1;
-    lsdcp_i += dtdt_i * r.condi1;
+    evapr_i -= dtdt_i * lvdcp * gdp;
+    evaps_i -= dtdt_i * lsdcp * gdp;
+    lvdcp_i += dtdt_i * (r.condl1 - evapr * gdp);
+    lsdcp_i += dtdt_i * (r.condi1 - evaps * gdp);
     o_lude -= dtdt_i * gdp * mix;
     lvdcp_i -= dtdt_i * x.lude * gdp * fwat;
     lsdcp_i -= dtdt_i * x.lude * gdp * (T(1.0) - fwat);
@@ -479,13 +539,71 @@ __device__ __forceinline__ ADOut<T> ad_backward(const Ext<T>& e, const NLK<T>& k
     lvdcp_i -= dtdt_i * r.rfreeze1 * gdp;
     lsdcp_i += dtdt_i * r.rfreeze1 * gdp;
     rfreeze_i += dtdt_i * (lsdcp - lvdcp) * gdp;
-    gdp_i += dqdt_i * x.lude;
+    gdp_i += dqdt_i * src;
     o_lude += dqdt_i * gdp;
+    evapr_i += dqdt_i * gdp;
+    evaps_i += dqdt_i * gdp;
     condl_i -= dqdt_i;
     condi_i -= dqdt_i;
-    // :710-719 (no evaporation): corqs_i = covpclr_i = covptot_i = daph_i = out_qsat_i = prtot_i = qlim_i = 0
+    // :635-719 evaporation block; without it (or on a level where it did not run, :710-719)
+    // corqs_i = covpclr_i = covptot_i = daph_i = out_qsat_i = prtot_i = qlim_i = 0
     T daph_i = T(0.0);
     T o_qsat = T(0.0);
+    T a_clc = f.clc;
+    T corqs_i = T(0.0), covpclr_i = T(0.0), covptot_i = T(0.0), qlim_i = T(0.0);
+    if constexpr (EVAP) {
+        if (r.ev) {
+            const T rpr = frcp<T>(r.prtot);
+            const T e_evaps_i = evaps_i - tmp_sfln_i;
+            tmp_sfln_i += r.dpr * e_evaps_i * rpr;
+            T dpr_i = r.sfln2 * e_evaps_i * rpr;
+            T prtot_i = -r.dpr * r.sfln2 * e_evaps_i * rpr * rpr;
+            const T e_evapr_i = evapr_i - tmp_rfln_i;
+            tmp_rfln_i += r.dpr * e_evapr_i * rpr;
+            dpr_i += r.rfln2 * e_evapr_i * rpr;
+            prtot_i -= r.dpr * r.rfln2 * e_evapr_i * rpr * rpr;
+            T cov_i = b.covptot_i + f.covptot;  // :653
+            if (r.all_evaporates) {             // preclr <= 0
+                a_clc += cov_i;
+                cov_i = T(0.0);
+            }
+            T preclr_i = T(0.0);
+            if (r.capped) {  // dpr1 > preclr1
+                preclr_i = dpr_i;
+                dpr_i = T(0.0);
+            }
+            const T rdtgdp = r.dp * frcp<T>(kc.rgdt);
+            const T b_i = r.covpclr * dpr_i * rdtgdp;
+            covpclr_i = r.b * dpr_i * rdtgdp;
+            const T dtgdp_i = -r.covpclr * r.b * dpr_i * rdtgdp * rdtgdp;
+            daph_i = dt * e.RG * dtgdp_i * r.rdp;
+            const T dqe = x.qsat - r.qe;
+            // the reference's dt**2 factors are kept (:667-672)
+            const T beta_i = dt * dqe * b_i * r.rtmp1 - dt * dt * r.beta * dqe * r.corqs * b_i * r.rtmp1 * r.rtmp1;
+            o_qsat = dt * r.beta * b_i * r.rtmp1;
+            T qe_i = -dt * r.beta * b_i * r.rtmp1;
+            corqs_i = -dt * dt * r.beta * dqe * r.beta * b_i * r.rtmp1 * r.rtmp1;
+            const T rcp = frcp<T>(r.covpclr);
+            const T raphs = frcp<T>(b.aph_s);
+            preclr_i += r.xx * r.sq * beta_i * rcp;
+            // sqrt(ap aph_s) = sq aph_s
+            o_ap += T(0.5) * r.xx * r.preclr1 * beta_i * rcp * frcp<T>(r.sq) * raphs;
+            b.aph_s_i -= T(0.5) * r.xx * r.preclr1 * r.sq * beta_i * rcp * raphs;
+            const T rcov1 = frcp<T>(r.covptot1);
+            const T romc2 = r.romc * r.romc;
+            covpclr_i += -(r.xx * r.preclr1 * r.sq * beta_i * rcp * rcp) - (x.qsat - r.qlim) * qe_i * romc2 +
+                         r.prtot * preclr_i * rcov1;
+            o_qsat += qe_i - r.covpclr * qe_i * romc2;
+            qlim_i = r.covpclr * qe_i * romc2;
+            a_clc -= T(2.0) * (x.qsat - r.qlim) * r.covpclr * qe_i * romc2 * r.romc;
+            prtot_i += r.covpclr * preclr_i * rcov1;
+            cov_i -= r.prtot * r.covpclr * preclr_i * rcov1 * rcov1;
+            covptot_i = cov_i;
+            // :722-723
+            tmp_rfln_i += prtot_i;
+            tmp_sfln_i += prtot_i;
+        }
+    }
     // :722-736
     const T dr_i = r.fwatr1 * tmp_rfln_i + (T(1.0) - r.fwatr1) * tmp_sfln_i;
     T prr_i;
@@ -499,7 +617,6 @@ __device__ __forceinline__ ADOut<T> ad_backward(const Ext<T>& e, const NLK<T>& k
     T prs_i = cons2 * r.dp * dr_i;
     dp_i += cons2 * (r.prr + r.prs) * dr_i;
     // :738-782
-    T a_clc = f.clc;
     if (r.cloudy) {
         prs_i -= qiwc_i;
         qiwc_i += prs_i;
@@ -553,7 +670,17 @@ __device__ __forceinline__ ADOut<T> ad_backward(const Ext<T>& e, const NLK<T>& k
     }
     b.tmp_rfln_i = tmp_rfln_i;
     b.tmp_sfln_i = tmp_sfln_i;
-    // :810-817: covpclr_i = covptot_i = 0 without the evaporation block -> no contribution
+    // :810-817 (covpclr_i = covptot_i = 0 without the evaporation block -> no contribution)
+    if constexpr (EVAP) {
+        if (r.covpclr1 < T(0.0)) covpclr_i = T(0.0);
+        covptot_i += covpclr_i;
+        a_clc -= covpclr_i;
+        if (r.out_clc > r.covptot) {  // :815, literal: tests the cover AFTER the evaporation block's reset
+            a_clc += covptot_i;
+            covptot_i = T(0.0);
+        }
+        b.covptot_i = covptot_i;
+    }
     // :820-825
     qiwc_i += condi_i * rdt;
     o_qi -= condi_i * rdt;
@@ -637,7 +764,12 @@ __device__ __forceinline__ ADOut<T> ad_backward(const Ext<T>& e, const NLK<T>& k
     o_qsat += qsat_i * r.supsat;
     const T supsat_i = qsat_i * x.qsat;
     if (r.t2 < e.RTICE) o_t -= T(0.003) * supsat_i;
-    // :941-967 (corqs_i = qlim_i = 0)
+    if constexpr (EVAP) {  // :933-938
+        if (r.q2 > x.qsat) o_qsat += qlim_i;
+        else o_q += qlim_i;
+        dqsdtemp_i += kc.cons3 * corqs_i;  // :941
+    }
+    // :941-967
     o_qsat += r.fac * r.cor * dqsdtemp_i;
     const T cor_i = r.fac * x.qsat * dqsdtemp_i;
     const T fac_i = r.cor * x.qsat * dqsdtemp_i;
@@ -691,7 +823,7 @@ __device__ __forceinline__ T ad_trpaus(const T* __restrict__ pt, const T* __rest
     return trpaus;
 }
 
-template <typename T, bool REG, bool FIX>
+template <typename T, bool REG, bool FIX, bool EVAP>
 __global__ void __launch_bounds__(kColBlock)
 ad_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, NL_NUM_IN> in,
           CPtrs<T, NL_NUM_OUT> adj, const T* __restrict__ eta, MPtrs<T, NL_NUM_OUT> out, MPtrs<T, NL_NUM_IN> oadj,
@@ -725,8 +857,10 @@ ad_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
     stg(out.p[NL_OUT_FPLSN], colb, T(0.0));
     stg(out.p[NL_OUT_FHPSL], colb, T(0.0));
     stg(out.p[NL_OUT_FHPSN], colb, T(0.0));
+    const T aph_s = EVAP ? ldg(in.p[NL_IN_APH], uint32_t(nz) * lsb + colb) : T(1.0);
+    T* const park = oadj.p[NL_IN_MFD];  // EVAP: level k holds the cover entering level k until sweep 2 overwrites it
     {
-        T rfl = T(0.0), sfl = T(0.0);
+        T rfl = T(0.0), sfl = T(0.0), covptot = T(0.0);
         T aph_k = ldg(in.p[NL_IN_APH], colb);
         uint32_t o = colb;
         ADIn<T> xa = ad_load<T>(in, lsb, o);
@@ -734,9 +868,12 @@ ad_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
             ADIn<T> xn = xa;
             if (k + 1 < nz) xn = ad_load<T>(in, lsb, o + lsb);
             ADTraj<T> r;
-            ad_forward<T, FIX>(e, kc, xk, xa, aph_k, k, s_eta[k], s_scalm[k], crh, dt, rfl, sfl, r);
+            ad_forward<T, FIX, EVAP>(e, kc, xk, xa, aph_k, k, s_eta[k], s_scalm[k], crh, dt, rfl, sfl, covptot, aph_s,
+                                     r);
+            if constexpr (EVAP) stg(park, o, covptot);
+            covptot = r.covptot;
             stg(out.p[NL_OUT_CLC], o, r.out_clc);
-            stg(out.p[NL_OUT_COVPTOT], o, T(0.0));
+            stg(out.p[NL_OUT_COVPTOT], o, r.out_covptot);
             stg(out.p[NL_OUT_TND_Q], o, r.tnd_q);
             stg(out.p[NL_OUT_TND_T], o, r.tnd_t);
             stg(out.p[NL_OUT_TND_QL], o, r.tnd_ql);
@@ -756,29 +893,33 @@ ad_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
     // ---------------- sweep 2: adjoint (:479-996), k = nz-1 .. 0
     ADBack<T> b;
     b.tmp_rfln_i = b.tmp_sfln_i = b.rfl_i = b.sfl_i = b.daph_i = b.dp_i = T(0.0);
+    b.covptot_i = b.aph_s_i = T(0.0);
+    b.aph_s = aph_s;
     {
         int k = nz - 1;
         uint32_t o = uint32_t(k) * lsb + colb;
         ADIn<T> xa = ad_load<T>(in, lsb, o);
-        ADForce<T> fa = ad_load_force<T>(adj, e, lsb, o);
+        ADForce<T> fa = ad_load_force<T, EVAP>(adj, e, lsb, o);
         T aph_k = ldg(in.p[NL_IN_APH], o);
         T sfl = ldg(const_cast<const T*>(out.p[NL_OUT_FPLSN]), o);
         T rfl = ldg(const_cast<const T*>(out.p[NL_OUT_FPLSL]), o);
+        T cov = EVAP ? ldg(const_cast<const T*>(park), o) : T(0.0);
         for (; k >= 0; --k) {
             ADIn<T> xn = xa;
             ADForce<T> fn = fa;
-            T aph_n = aph_k, sfl_n = sfl, rfl_n = rfl;
+            T aph_n = aph_k, sfl_n = sfl, rfl_n = rfl, cov_n = cov;
             if (k > 0) {
                 const uint32_t om = o - lsb;
                 xn = ad_load<T>(in, lsb, om);
-                fn = ad_load_force<T>(adj, e, lsb, om);
+                fn = ad_load_force<T, EVAP>(adj, e, lsb, om);
                 aph_n = ldg(in.p[NL_IN_APH], om);
                 sfl_n = ldg(const_cast<const T*>(out.p[NL_OUT_FPLSN]), om);
                 rfl_n = ldg(const_cast<const T*>(out.p[NL_OUT_FPLSL]), om);
+                if constexpr (EVAP) cov_n = ldg(const_cast<const T*>(park), om);
             }
             ADTraj<T> r;
-            ad_forward<T, FIX>(e, kc, xk, xa, aph_k, k, s_eta[k], s_scalm[k], crh, dt, rfl, sfl, r);
-            const ADOut<T> a = ad_backward<T, REG, FIX>(e, kc, xa, k, s_scalm[k], dt, sfl, r, fa, b);
+            ad_forward<T, FIX, EVAP>(e, kc, xk, xa, aph_k, k, s_eta[k], s_scalm[k], crh, dt, rfl, sfl, cov, aph_s, r);
+            const ADOut<T> a = ad_backward<T, REG, FIX, EVAP>(e, kc, xa, k, s_scalm[k], dt, sfl, r, fa, b);
             stg(oadj.p[NL_IN_AP], o, a.ap);
             stg(oadj.p[NL_IN_T], o, a.t);
             stg(oadj.p[NL_IN_Q], o, a.q);
@@ -800,8 +941,13 @@ ad_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
             aph_k = aph_n;
             sfl = sfl_n;
             rfl = rfl_n;
+            cov = cov_n;
             o -= lsb;
         }
+    }
+    if constexpr (EVAP) {  // :970-971: out_aph_i[nz] also receives the accumulated tmp_aph_s_i
+        const uint32_t on = uint32_t(nz) * lsb + colb;
+        stg(oadj.p[NL_IN_APH], on, ldg(const_cast<const T*>(oadj.p[NL_IN_APH]), on) + b.aph_s_i);
     }
     // :982-986 top half level
     stg(oadj.p[NL_IN_APH], colb, b.daph_i - b.dp_i);
@@ -811,7 +957,7 @@ ad_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
 template <typename T>
 int launch_ad(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* const* in, const T* const* in_adj,
               const T* eta, T* const* out, T* const* out_adj, double dt, hipStream_t stream) {
-    if (p.LEVAPLS2 || p.LDRAIN1D) return -2;
+    const bool evap = p.LEVAPLS2 || p.LDRAIN1D;
     const Ext<T> e = make_ext<T>(p);
     CPtrs<T, NL_NUM_IN> ci;
     CPtrs<T, NL_NUM_OUT> ca;
@@ -822,17 +968,23 @@ int launch_ad(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
     const dim3 grid((nx + kColBlock - 1) / kColBlock), block(kColBlock);
     const size_t smem = 2 * size_t(nz + 1) * sizeof(T);
     const T tdt = static_cast<T>(dt);
-    const NLK<T> kc = make_nlk<T>(p, dt, false);
+    const NLK<T> kc = make_nlk<T>(p, dt, evap);
     const ExpK<T> xk = make_expk<T>();
     if (!fits_u32_offsets<T>(nz, ls)) return -2;
     const bool reg = p.LREGCL != 0;
     const bool fix = p.AD_TRAJ_FIX != 0;
-#define CS2_AD_LAUNCH(R, F) \
-    hipLaunchKernelGGL((ad_kernel<T, R, F>), grid, block, smem, stream, e, kc, xk, nx, nz, ls, ci, ca, eta, co, coa, tdt)
-    if (reg && !fix) CS2_AD_LAUNCH(true, false);
-    else if (!reg && !fix) CS2_AD_LAUNCH(false, false);
-    else if (reg && fix) CS2_AD_LAUNCH(true, true);
-    else CS2_AD_LAUNCH(false, true);
+#define CS2_AD_LAUNCH(R, F, E)                                                                                         \
+    hipLaunchKernelGGL((ad_kernel<T, R, F, E>), grid, block, smem, stream, e, kc, xk, nx, nz, ls, ci, ca, eta, co, coa, \
+                       tdt)
+#define CS2_AD_LAUNCH_E(R, F) \
+    do {                      \
+        if (evap) CS2_AD_LAUNCH(R, F, true); else CS2_AD_LAUNCH(R, F, false); \
+    } while (0)
+    if (reg && !fix) CS2_AD_LAUNCH_E(true, false);
+    else if (!reg && !fix) CS2_AD_LAUNCH_E(false, false);
+    else if (reg && fix) CS2_AD_LAUNCH_E(true, true);
+    else CS2_AD_LAUNCH_E(false, true);
+#undef CS2_AD_LAUNCH_E
 #undef CS2_AD_LAUNCH
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

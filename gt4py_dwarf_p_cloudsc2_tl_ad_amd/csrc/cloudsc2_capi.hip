@@ -124,9 +124,6 @@ int ad_impl(const char* fn, const Cloudsc2Params* p, int32_t nx, int32_t nz, int
     if (p->ICALL != 0) return fail(CLOUDSC2_E_UNSUPPORTED, "%s: ICALL=%d unsupported", fn, p->ICALL);
     if (!(dt > 0.0)) return fail(CLOUDSC2_E_ARG, "%s: dt=%g must be > 0", fn, dt);
     if (p->NLEV != nz) return fail(CLOUDSC2_E_ARG, "%s: NLEV=%d != nz=%d", fn, p->NLEV, nz);
-    if (p->LEVAPLS2 || p->LDRAIN1D)
-        return fail(CLOUDSC2_E_UNSUPPORTED,
-                    "%s: LEVAPLS2/LDRAIN1D (precipitation-evaporation block) has no AD kernel instantiation", fn);
     if (nx == 0) return CLOUDSC2_OK;
     return launched(fn, cs2::launch_ad<T>(*p, nx, nz, ls, in, in_adj, eta, out, out_adj, dt, static_cast<hipStream_t>(stream)));
 }

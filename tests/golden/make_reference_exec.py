@@ -90,9 +90,10 @@ def main():
 
     klevel = np.arange(0, NZ + 1)
 
-    def run_tl(e, inc_tag):
+    def run_tl(e, inc_tag, dt=dt, src=None):
+        src = out if src is None else src
         f = {k: v.copy() for k, v in ins.items()}
-        f.update({"in_" + n + "_i": out[f"{inc_tag}_{n}_i"].copy() for n in NL_IN})
+        f.update({"in_" + n + "_i": src[f"{inc_tag}_{n}_i"].copy() for n in NL_IN})
         f["in_eta"] = eta
         f["tmp_klevel"] = klevel
         for n in NL_OUT:
@@ -116,12 +117,12 @@ def main():
     # (no AD vector with LEVAPLS2: on these columns the reference's own TL evaporation block already
     #  produces perturbations of order 1e43 - "the code never enters this branch when input data are
     #  retrieved from input.h5", tangent_linear/_stencils/cloudsc2.py:529-530 - so its adjoint is noise)
-    for tag, e, tl_tag in (("ad", ext, "tl_sym"), ("ad_noreg", {**ext, "LREGCL": False}, "tl_sym")):
+    def run_ad(e, forcing, dt=dt):
         f = {k: v.copy() for k, v in ins.items()}
         f["in_eta"] = eta
         f["tmp_klevel"] = klevel
         for n in NL_OUT:
-            f["in_" + n + "_i"] = out[f"{tl_tag}_out_{n}_i"].copy()
+            f["in_" + n + "_i"] = forcing[n].copy()
             f["out_" + n] = zeros()
         for n in NL_IN:
             f["out_" + n + "_i"] = zeros()
@@ -129,6 +130,10 @@ def main():
                   "tmp_trpaus"):
             f[n] = ij()
         Executor(defs, e).run("cloudsc2_ad", f, {"dt": dt}, NZ)
+        return f
+
+    for tag, e, tl_tag in (("ad", ext, "tl_sym"), ("ad_noreg", {**ext, "LREGCL": False}, "tl_sym")):
+        f = run_ad(e, {n: out[f"{tl_tag}_out_{n}_i"] for n in NL_OUT})
         for n in NL_OUT:
             out[f"{tag}_out_{n}"] = f["out_" + n]
         for n in NL_IN:
@@ -137,6 +142,30 @@ def main():
     path = os.path.join(HERE, "reference_exec.npz")
     np.savez_compressed(path, **out)
     print(path, len(out), "arrays", os.path.getsize(path) // 1024, "KiB")
+
+    # ---- evaporation block of TL and AD (LEVAPLS2) at dt = 60 s with increments that are NOT proportional to
+    # the state: at the drivers' 3600 s the reference's TL recurrence amplifies rounding noise (its b_i carries
+    # dt**2 where the derivative has dt, tangent_linear/_stencils/cloudsc2.py:565-569) and a uniform 1 % scaling
+    # is nearly a symmetry of the scheme, so the vectors above cannot pin this block.  Same inputs as above.
+    ev = {"dt": np.float64(60.0)}
+    rng = np.random.default_rng(SEED)
+    for n in NL_IN:
+        ev[f"inc_{n}_i"] = 0.01 * ins["in_" + n] * rng.uniform(0.5, 1.5, size=ins["in_" + n].shape)
+    ev["inc_supsat_i"][...] = 0.0
+    for tag, e in (("tl_evap", evap), ("tl_evap_noreg", {**evap, "LREGCL": False})):
+        f = run_tl(e, "inc", dt=60.0, src=ev)
+        for n in NL_OUT:
+            ev[f"{tag}_out_{n}"] = f["out_" + n]
+            ev[f"{tag}_out_{n}_i"] = f["out_" + n + "_i"]
+    for tag, e, tl_tag in (("ad_evap", evap, "tl_evap"), ("ad_evap_noreg", {**evap, "LREGCL": False}, "tl_evap_noreg")):
+        f = run_ad(e, {n: ev[f"{tl_tag}_out_{n}_i"] for n in NL_OUT}, dt=60.0)
+        for n in NL_OUT:
+            ev[f"{tag}_out_{n}"] = f["out_" + n]
+        for n in NL_IN:
+            ev[f"{tag}_out_{n}_i"] = f["out_" + n + "_i"]
+    path = os.path.join(HERE, "reference_exec_evap.npz")
+    np.savez_compressed(path, **ev)
+    print(path, len(ev), "arrays", os.path.getsize(path) // 1024, "KiB")
 
 
 if __name__ == "__main__":

@@ -277,10 +277,26 @@ def test_tl_evaporation_block_at_the_driver_timestep(gpu):
         assert np.abs(got_i[n][:k] - want_i[n][:k]).max() <= 1e-9 * np.abs(want_i[n][:k]).max()
 
 
-def test_ad_rejects_evaporation_switch(gpu):
-    """LEVAPLS2 / LDRAIN1D have no AD instantiation: the call must raise, not compute something else."""
-    ext = externals(NLEV=137, LEVAPLS2=True)
-    fields, eta, dt = nl_case(64)
-    forcing = {n: np.zeros_like(fields["in_ap"]) for n in NL_OUT}
-    with pytest.raises(ValueError, match="LEVAPLS2"):
-        run_hip_ad(fields, forcing, eta, dt, ext, gpu, 64, 137)
+@pytest.mark.parametrize("sw", [dict(LEVAPLS2=True, LREGCL=False), dict(LDRAIN1D=True, LREGCL=True),
+                                dict(LEVAPLS2=True, LREGCL=True, AD_TRAJ_FIX=1)])
+def test_ad_evaporation_block_matches_oracle(gpu, sw):
+    """cloudsc2_ad with the evaporation block (adjoint/_stencils/cloudsc2.py:357-394, :635-719) at dt = 60 s, forced
+    with the oracle's TL output perturbations of non-proportional increments.  (The reference's AD evaporation block is
+    NOT the transpose of its TL one - the symmetry norm is O(1e16) eps already in the oracle - so there is no symmetry
+    test for this switch, only parity.)"""
+    nx, dt = 333, 60.0
+    ext = externals(NLEV=137, **sw)
+    fields, eta, _ = nl_case(nx, ext=ext)
+    rng = np.random.default_rng(5)
+    fi = {k: v * rng.uniform(0.5, 1.5, size=v.shape) for k, v in increments(fields, 0.01, ignore_supsat=True).items()}
+    _, forcing = run_oracle_tl(fields, fi, eta, dt, ext)
+    want, want_i = run_oracle_ad(fields, forcing, eta, dt, ext)
+    got, got_i = run_hip_ad(fields, forcing, eta, dt, ext, gpu, nx, 137)
+    assert np.abs(want["covptot"]).max() > 0
+    for n in NL_OUT:
+        k = nlev_of(n, 137)
+        _assert_close_by_column(f"ad-evap out_{n}", got[n][:k], want[n][:k], 1e-9)
+    for n in NL_IN:
+        k = 138 if n in ("aph", "lu") else 137
+        # out_lu_i inherits the cancellation inside a_clc (tests/test_reference_exec.py)
+        _assert_close_by_column(f"ad-evap out_{n}_i", got_i[n][:k], want_i[n][:k], 1e-4 if n == "lu" else 1e-8)

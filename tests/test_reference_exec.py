@@ -77,6 +77,43 @@ def test_oracle_ad_matches_reference_source(gold, tag, flags, tl_tag):
             assert np.array_equal(oi[n], want), (tag, n)
 
 
+@pytest.fixture(scope="module")
+def gold_evap(gold):
+    """Evaporation block of TL / AD executed from the reference source at dt = 60 s with non-proportional increments
+    (tests/golden/make_reference_exec.py explains why): same inputs as `gold`."""
+    ev = np.load(os.path.join(HERE, "golden", "reference_exec_evap.npz"))
+    return ev, {"in_" + n + "_i": ev[f"inc_{n}_i"] for n in NL_IN}, float(ev["dt"])
+
+
+@pytest.mark.parametrize("tag,flags", [("tl_evap", {}), ("tl_evap_noreg", dict(LREGCL=False))])
+def test_oracle_tl_evaporation_bit_exact(gold, gold_evap, tag, flags):
+    _, fields, eta, _ = gold
+    ev, fi, dt = gold_evap
+    o, oi = run_oracle_tl(fields, fi, eta, dt, externals(NLEV=NZ, LEVAPLS2=True, **flags))
+    assert (ev[f"{tag}_out_covptot"] > 0).any() and (ev[f"{tag}_out_covptot_i"] != 0).any()
+    for n in NL_OUT:
+        assert np.array_equal(o[n], ev[f"{tag}_out_{n}"]), (tag, n)
+        assert np.array_equal(oi[n], ev[f"{tag}_out_{n}_i"]), (tag, n + "_i")
+
+
+@pytest.mark.parametrize("tag,flags,tl_tag", [("ad_evap", {}, "tl_evap"),
+                                              ("ad_evap_noreg", dict(LREGCL=False), "tl_evap_noreg")])
+def test_oracle_ad_evaporation_matches_reference_source(gold, gold_evap, tag, flags, tl_tag):
+    _, fields, eta, _ = gold
+    ev, _, dt = gold_evap
+    forcing = {n: ev[f"{tl_tag}_out_{n}_i"] for n in NL_OUT}
+    o, oi = run_oracle_ad(fields, forcing, eta, dt, externals(NLEV=NZ, LEVAPLS2=True, **flags))
+    for n in NL_OUT:
+        assert np.array_equal(o[n], ev[f"{tag}_out_{n}"]), (tag, n)
+    for n in NL_IN:
+        # not bit-identical (the oracle groups a few sums differently), so judged on each column's own scale;
+        # out_lu_i = -(...) * a_clc inherits the cancellation inside a_clc (|terms| ~ 1e8 x |sum|) in 2-3 columns
+        want = ev[f"{tag}_out_{n}_i"]
+        scale = np.abs(want).max(axis=0, keepdims=True)
+        tol = 1e-6 if n == "lu" else 1e-12
+        assert (np.abs(oi[n] - want) <= tol * scale).all(), (tag, n, np.abs(oi[n] - want).max())
+
+
 def test_oracle_increment_and_perturbation_bit_exact(gold):
     g, fields, _, _ = gold
     st = {n: g["in_" + n] for n in INC}
@@ -133,6 +170,49 @@ def test_hip_ad_matches_reference_source(gpu, gold, tag, flags):
     for n in NL_IN:
         k = 138 if n in ("aph", "lu") else 137
         assert_close(f"{tag} out_{n}_i", got_i[n][:k], g[f"{tag}_out_{n}_i"][:k], rtol_mul=1000.0)
+
+
+def _close_by_column(name, got, want, tol):
+    assert not np.isnan(got).any(), name
+    scale = np.abs(want).max(axis=0, keepdims=True)
+    err = np.abs(got - want)
+    assert (err <= tol * scale + np.finfo(np.float64).tiny).all(), \
+        f"{name}: worst {np.max(err / (scale + 1e-300)):.2e} of the column scale (tol {tol:.0e})"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,flags", [("tl_evap", {}), ("tl_evap_noreg", dict(LREGCL=False))])
+def test_hip_tl_evaporation_matches_reference_source(gpu, gold, gold_evap, tag, flags):
+    from test_hip_tl_ad import run_hip_tl
+
+    _, fields, eta, _ = gold
+    ev, fi, dt = gold_evap
+    ext = externals(NLEV=NZ, LEVAPLS2=True, **flags)
+    got, got_i = run_hip_tl(fields, fi, eta, dt, ext, gpu, fields["in_ap"].shape[1], NZ)
+    for n in NL_OUT:
+        k = nlev_of(n, NZ)
+        _close_by_column(f"{tag} out_{n}", got[n][:k], ev[f"{tag}_out_{n}"][:k], 1e-9)
+        _close_by_column(f"{tag} out_{n}_i", got_i[n][:k], ev[f"{tag}_out_{n}_i"][:k], 1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,flags,tl_tag", [("ad_evap", {}, "tl_evap"),
+                                              ("ad_evap_noreg", dict(LREGCL=False), "tl_evap_noreg")])
+def test_hip_ad_evaporation_matches_reference_source(gpu, gold, gold_evap, tag, flags, tl_tag):
+    from test_hip_tl_ad import run_hip_ad
+
+    _, fields, eta, _ = gold
+    ev, _, dt = gold_evap
+    forcing = {n: ev[f"{tl_tag}_out_{n}_i"] for n in NL_OUT}
+    ext = externals(NLEV=NZ, LEVAPLS2=True, **flags)
+    got, got_i = run_hip_ad(fields, forcing, eta, dt, ext, gpu, fields["in_ap"].shape[1], NZ)
+    for n in NL_OUT:
+        k = nlev_of(n, NZ)
+        _close_by_column(f"{tag} out_{n}", got[n][:k], ev[f"{tag}_out_{n}"][:k], 1e-9)
+    for n in NL_IN:
+        k = 138 if n in ("aph", "lu") else 137
+        # out_lu_i: see test_oracle_ad_evaporation_matches_reference_source (cancellation inside a_clc)
+        _close_by_column(f"{tag} out_{n}_i", got_i[n][:k], ev[f"{tag}_out_{n}_i"][:k], 1e-4 if n == "lu" else 1e-9)
 
 
 @pytest.mark.gpu

@@ -478,6 +478,213 @@ nl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// LDS-ring variant of the sweep (plain cloudsc2_nl, FUSE = 0).  Same prologue, same nl_level / nl_store; only the
+// way the 16 input words of a level reach the lane differs:
+//   * every wave owns RD slots of 16 fields x 64 columns in LDS; the inputs of level k + RD - 1 are requested with
+//     LDS-DMA (`global_load_lds_dwordx4`, no VGPR destination) while level k is computed, so RD - 1 levels are in
+//     flight instead of the one level the register prefetch can afford at 240 VGPRs - at one wave per SIMD
+//     (65 536 columns) that is the only source of memory-level parallelism (profiles/microbench_ring.hip);
+//   * one DMA instruction moves 16 B per lane = NPL columns (2 fp64 / 4 fp32): the wave's lanes are split into
+//     NPL groups, group g fetches field i*NPL + g for the wave's 64 columns, so the LDS image of instruction i
+//     is [field i*NPL .. i*NPL+NPL-1][64 columns] (the DMA destination is lane-linear) and field f of a slot
+//     starts at f * 64 * sizeof(T); the lane then reads its own column with ds_read_b64 / _b32;
+//   * the waits are counted by hand: the DMAs of level k are older than (RD-1) x (NI DMAs + 10 stores), and vmcnt
+//     retires in order on gfx9 (the wait used is one level of stores stricter than that, see NFULL).  The wait and the LDS reads live in ONE asm statement with a memory clobber: hipcc
+//     would otherwise drain vmcnt(0) before every LDS read that follows an LDS-DMA, and no store may move across
+//     the wait (the count must never exceed the operations really issued after level k's DMAs).
+// Used when the launcher can guarantee 16-byte aligned rows and whole waves (launch_nl); every other call takes
+// the register-prefetch kernel above.  Results are bit-identical (same arithmetic on the same words).
+#ifndef CS2_NL_RING
+#define CS2_NL_RING 3   // slots per wave (levels in flight + the one being computed); 0 disables the variant
+#endif
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* glb_void_ptr;
+
+template <typename T>
+struct RingGeom {
+    static constexpr int NPL = 16 / int(sizeof(T));               // columns per lane per DMA = fields per DMA
+    static constexpr int NI = NL_NUM_IN / NPL;                    // DMA instructions per level
+    static constexpr int SLOT = NL_NUM_IN * 64 * int(sizeof(T));  // bytes per wave per level
+    static constexpr int NSTORE = NL_NUM_OUT;                     // stores per level (nl_store)
+};
+
+// Wait until at most N vector-memory operations are outstanding, then read this lane's column of the 16 fields from
+// the slot at LDS byte address `a` and the level's table entries at `ta` (eta) / `tb` (scalm).
+template <int N>
+__device__ __forceinline__ void ring_read(uint32_t a, uint32_t ta, uint32_t tb, NLIn<double>& x, double& eta_k,
+                                          double& scalm_k) {
+    asm volatile(
+        "s_waitcnt vmcnt(%21)\n\t"
+            "ds_read_b64 %0, %18\n\t"
+            "ds_read_b64 %1, %18 offset:512\n\t"
+            "ds_read_b64 %2, %18 offset:1024\n\t"
+            "ds_read_b64 %3, %18 offset:1536\n\t"
+            "ds_read_b64 %4, %18 offset:2048\n\t"
+            "ds_read_b64 %5, %18 offset:2560\n\t"
+            "ds_read_b64 %6, %18 offset:3072\n\t"
+            "ds_read_b64 %7, %18 offset:3584\n\t"
+            "ds_read_b64 %8, %18 offset:4096\n\t"
+            "ds_read_b64 %9, %18 offset:4608\n\t"
+            "ds_read_b64 %10, %18 offset:5120\n\t"
+            "ds_read_b64 %11, %18 offset:5632\n\t"
+            "ds_read_b64 %12, %18 offset:6144\n\t"
+            "ds_read_b64 %13, %18 offset:6656\n\t"
+            "ds_read_b64 %14, %18 offset:7168\n\t"
+            "ds_read_b64 %15, %18 offset:7680\n\t"
+            "ds_read_b64 %16, %19\n\t"
+            "ds_read_b64 %17, %20\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(x.ap), "=&v"(x.aph1), "=&v"(x.lu1), "=&v"(x.lude), "=&v"(x.mfd), "=&v"(x.mfu), "=&v"(x.q), "=&v"(x.qi),
+          "=&v"(x.ql), "=&v"(x.qsat), "=&v"(x.supsat), "=&v"(x.t), "=&v"(x.tq), "=&v"(x.tqi), "=&v"(x.tql), "=&v"(x.tt),
+          "=&v"(eta_k), "=&v"(scalm_k)
+        : "v"(a), "v"(ta), "v"(tb), "n"(N)
+        : "memory");
+}
+template <int N>
+__device__ __forceinline__ void ring_read(uint32_t a, uint32_t ta, uint32_t tb, NLIn<float>& x, float& eta_k,
+                                          float& scalm_k) {
+    asm volatile(
+        "s_waitcnt vmcnt(%21)\n\t"
+            "ds_read_b32 %0, %18\n\t"
+            "ds_read_b32 %1, %18 offset:256\n\t"
+            "ds_read_b32 %2, %18 offset:512\n\t"
+            "ds_read_b32 %3, %18 offset:768\n\t"
+            "ds_read_b32 %4, %18 offset:1024\n\t"
+            "ds_read_b32 %5, %18 offset:1280\n\t"
+            "ds_read_b32 %6, %18 offset:1536\n\t"
+            "ds_read_b32 %7, %18 offset:1792\n\t"
+            "ds_read_b32 %8, %18 offset:2048\n\t"
+            "ds_read_b32 %9, %18 offset:2304\n\t"
+            "ds_read_b32 %10, %18 offset:2560\n\t"
+            "ds_read_b32 %11, %18 offset:2816\n\t"
+            "ds_read_b32 %12, %18 offset:3072\n\t"
+            "ds_read_b32 %13, %18 offset:3328\n\t"
+            "ds_read_b32 %14, %18 offset:3584\n\t"
+            "ds_read_b32 %15, %18 offset:3840\n\t"
+            "ds_read_b32 %16, %19\n\t"
+            "ds_read_b32 %17, %20\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(x.ap), "=&v"(x.aph1), "=&v"(x.lu1), "=&v"(x.lude), "=&v"(x.mfd), "=&v"(x.mfu), "=&v"(x.q), "=&v"(x.qi),
+          "=&v"(x.ql), "=&v"(x.qsat), "=&v"(x.supsat), "=&v"(x.t), "=&v"(x.tq), "=&v"(x.tqi), "=&v"(x.tql), "=&v"(x.tt),
+          "=&v"(eta_k), "=&v"(scalm_k)
+        : "v"(a), "v"(ta), "v"(tb), "n"(N)
+        : "memory");
+}
+
+template <typename T, bool EVAP, bool LIN, bool PINK, int RD>
+__global__ void __launch_bounds__(kColBlock, 1)
+nl_ring_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, NL_NUM_IN> in,
+               const T* __restrict__ eta, MPtrs<T, NL_NUM_OUT> out, T dt) {
+    using G = RingGeom<T>;
+    static_assert(kColBlock % 64 == 0 && RD >= 2, "whole waves, at least one level in flight");
+    static_assert((RD - 1) * (G::NI + G::NSTORE) < 64, "vmcnt is a 6-bit counter");
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    T* s_eta = reinterpret_cast<T*>(smem_raw);
+    T* s_scalm = s_eta + (nz + 1);
+    int klo, khi;
+    build_level_table<T>(eta, nz, e, s_eta, s_scalm, klo, khi);
+    if constexpr (PINK && CS2_NL_PINK) {
+        pin_vgpr(e.RCPD); pin_vgpr(e.RLSTT); pin_vgpr(e.RLVTT); pin_vgpr(e.R4LES); pin_vgpr(e.R4IES);
+        pin_vgpr(e.RTT); pin_vgpr(e.RLPTRC); pin_vgpr(e.R3IES); pin_vgpr(e.R3LES); pin_vgpr(e.R2ES);
+        pin_vgpr(e.ZQMAX); pin_vgpr(e.RETV); pin_vgpr(e.R5LES); pin_vgpr(e.R5IES); pin_vgpr(e.RTICE);
+        pin_vgpr(e.RG); pin_vgpr(e.RD); pin_vgpr(e.R5ALVCP); pin_vgpr(e.RALVDCP); pin_vgpr(e.R5ALSCP);
+        pin_vgpr(e.RALSDCP); pin_vgpr(kc.rdt); pin_vgpr(kc.cons2); pin_vgpr(kc.rRD); pin_vgpr(kc.rRCPD);
+        pin_vgpr(kc.cormax); pin_vgpr(kc.fw2); pin_vgpr(dt);
+    }
+    if constexpr (PINK && CS2_NL_PINX && CS2_NL_FEXP) {
+        pin_vgpr(xk.l2e); pin_vgpr(xk.ln2h); pin_vgpr(xk.ln2l); pin_vgpr(xk.c12); pin_vgpr(xk.c11);
+        pin_vgpr(xk.c10); pin_vgpr(xk.c9); pin_vgpr(xk.c8); pin_vgpr(xk.c7); pin_vgpr(xk.c6);
+        pin_vgpr(xk.c5); pin_vgpr(xk.c4); pin_vgpr(xk.c3);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wcol0 = blockIdx.x * kColBlock + wave * 64;   // first column of this wave
+    if (wcol0 >= nx) return;                                // nx % 64 == 0 (launcher): whole waves retire; the only
+                                                            // workgroup barrier is inside build_level_table
+    const uint32_t lsb = uint32_t(ls) * uint32_t(sizeof(T));
+    const uint32_t colb = uint32_t(wcol0 + lane) * uint32_t(sizeof(T));
+
+    const T trpaus = nl_trpaus<T>(in.p[NL_IN_T], in.p[NL_IN_TND_CML_T], lsb, colb, dt, s_eta, klo, khi);
+    const CrhCol<T> crh = crh_setup<T>(trpaus);
+
+    // :93-100
+    NLCarry<T> c;
+    c.rfl = T(0.0);
+    c.sfl = T(0.0);
+    c.covptot = T(0.0);
+    c.aph_k = ldg(in.p[NL_IN_APH], colb);
+    const T aph_s = EVAP ? ldg(in.p[NL_IN_APH], uint32_t(nz) * lsb + colb) : T(1.0);
+    stg(out.p[NL_OUT_FPLSL], colb, T(0.0));
+    stg(out.p[NL_OUT_FPLSN], colb, T(0.0));
+    stg(out.p[NL_OUT_FHPSL], colb, T(0.0));
+    stg(out.p[NL_OUT_FHPSN], colb, T(0.0));
+    // consume the prologue's ordinary loads BEFORE the first DMA is issued: hipcc drains vmcnt(0) at the first use of
+    // an ordinary load's result while an LDS-DMA is in flight, which would empty the ring inside level 0
+    pin_vgpr(c.aph_k);
+    if constexpr (EVAP) { T a = aph_s; pin_vgpr(a); }
+
+    // per-lane DMA sources: lane group g of instruction i walks field i*NPL + g, NPL adjacent columns per lane;
+    // aph and lu are read one half level below (aph[k+1], lu[k+1]: :130, :212)
+    constexpr int LPG = 64 / G::NPL;   // lanes per group
+    const int g = lane / LPG, l = lane % LPG;
+    const char* src[G::NI];
+#pragma unroll
+    for (int i = 0; i < G::NI; ++i) {
+        const T* base = in.p[i * G::NPL];
+        int f = i * G::NPL;
+#pragma unroll
+        for (int j = 1; j < G::NPL; ++j)
+            if (g == j) {
+                base = in.p[i * G::NPL + j];
+                f = i * G::NPL + j;
+            }
+        const uint32_t lev1 = (f == NL_IN_APH || f == NL_IN_LU) ? lsb : 0u;
+        src[i] = reinterpret_cast<const char*>(base) + (uint32_t(wcol0 + G::NPL * l) * uint32_t(sizeof(T)) + lev1);
+    }
+    // LDS: [eta | scalm table][pad][wave 0: RD slots][wave 1: RD slots] ...
+    const uint32_t tab_bytes = (2u * uint32_t(nz + 1) * uint32_t(sizeof(T)) + 1023u) & ~1023u;
+    const uint32_t ring0 = tab_bytes + uint32_t(wave) * uint32_t(RD * G::SLOT);
+    auto issue = [&](int slot) {
+#pragma unroll
+        for (int i = 0; i < G::NI; ++i) {
+            __builtin_amdgcn_global_load_lds((glb_void_ptr)src[i],
+                                             (lds_void_ptr)(&smem_raw[ring0 + uint32_t(slot * G::SLOT + i * 1024)]),
+                                             16, 0, CS2_NT & 1 ? 2 : 0);
+            src[i] += lsb;
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < RD - 1; ++j)
+        if (j < nz) issue(j);
+
+    // Operations younger than level k's DMAs when level k is read (k >= RD-1): (RD-1) x (NI DMAs + NSTORE stores).
+    // The wait must never ALLOW more than were really issued, so it is set one level of stores short of that: the
+    // stores it additionally retires are >= RD-1 levels old (long complete), and the count stays valid even if a
+    // future compiler merged or dropped stores of a level.  First RD-1 levels: no stores counted at all.
+    constexpr int NFULL = (RD - 1) * G::NI + (RD - 2) * G::NSTORE;
+    constexpr int NHEAD = (RD - 1) * G::NI;
+    const uint32_t rd_lane = ring0 + uint32_t(lane) * uint32_t(sizeof(T));
+    const uint32_t tb_off = uint32_t(nz + 1) * uint32_t(sizeof(T));
+    uint32_t o = colb;
+    int slot = 0, pslot = RD - 1;
+    for (int k = 0; k < nz; ++k) {
+        const bool more = k + RD - 1 < nz;
+        if (more) issue(pslot);
+        NLIn<T> x;
+        T eta_k, scalm_k;
+        const uint32_t a = rd_lane + uint32_t(slot * G::SLOT);
+        const uint32_t ta = uint32_t(k) * uint32_t(sizeof(T));
+        if (!more) ring_read<0>(a, ta, ta + tb_off, x, eta_k, scalm_k);            // tail: nothing left in flight
+        else if (k < RD - 1) ring_read<NHEAD>(a, ta, ta + tb_off, x, eta_k, scalm_k);
+        else ring_read<NFULL>(a, ta, ta + tb_off, x, eta_k, scalm_k);
+        const NLOut<T> r = nl_level<T, EVAP, LIN>(e, kc, xk, x, eta_k, scalm_k, crh, dt, aph_s, c);
+        nl_store<T>(out, e, lsb, o, r);
+        o += lsb;
+        slot = slot + 1 == RD ? 0 : slot + 1;
+        pslot = pslot + 1 == RD ? 0 : pslot + 1;
+    }
+}
+
 template <typename T>
 int launch_nl(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* const* in, const T* eta, T* const* out,
               double dt, hipStream_t stream, const T* const* in_i = nullptr, double pf = 0.0, T* qsat_out = nullptr) {
@@ -510,6 +717,34 @@ int launch_nl(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
         else if (!evap && lin) CS2_NL_LAUNCH(false, true, FU); \
         else CS2_NL_LAUNCH(false, false, FU);              \
     } while (0)
+#if CS2_NL_RING
+    // LDS-ring variant: whole waves, 16-byte aligned rows of every input field (the DMA moves 16 B per lane)
+    bool ring = fuse == 0 && nx % 64 == 0 && nz >= CS2_NL_RING && (ls * int64_t(sizeof(T))) % 16 == 0;
+    for (int i = 0; i < NL_NUM_IN && ring; ++i) ring = reinterpret_cast<uintptr_t>(in[i]) % 16 == 0;
+    if (ring) {
+        using G = RingGeom<T>;
+        const size_t tab = (2 * size_t(nz + 1) * sizeof(T) + 1023) & ~size_t(1023);
+        const size_t rsmem = tab + size_t(kColBlock / 64) * CS2_NL_RING * G::SLOT;
+#define CS2_NL_RING_LAUNCH(EV, LN)                                                                                   \
+    do {                                                                                                             \
+        auto kern = nl_ring_kernel<T, EV, LN, sizeof(T) == 8, CS2_NL_RING>;                                          \
+        static bool attr_set = false; /* > 64 KB of dynamic LDS needs the opt-in, once per instantiation */          \
+        if (!attr_set) {                                                                                             \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    int(rsmem)) != hipSuccess)                                                       \
+                return -1;                                                                                           \
+            attr_set = true;                                                                                         \
+        }                                                                                                            \
+        hipLaunchKernelGGL(kern, grid, block, rsmem, stream, e, kc, xk, nx, nz, ls, ci, eta, co, tdt);               \
+    } while (0)
+        if (evap && lin) CS2_NL_RING_LAUNCH(true, true);
+        else if (evap && !lin) CS2_NL_RING_LAUNCH(true, false);
+        else if (!evap && lin) CS2_NL_RING_LAUNCH(false, true);
+        else CS2_NL_RING_LAUNCH(false, false);
+#undef CS2_NL_RING_LAUNCH
+        return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
+#endif
     if (fuse == 0) CS2_NL_FLAGS(0);
     else if (fuse == 1) CS2_NL_FLAGS(1);
     else CS2_NL_FLAGS(2);

@@ -37,7 +37,8 @@ def core(args):
     io = ctx["io_config"]
     if io.output_csv_file is not None:
         write_performance_to_csv(io.output_csv_file, io.host_name, cfg.precision, "nl-" + cfg.gt4py_config.backend,
-                                 ctx["nx"], cfg.num_threads, 1, cfg.num_runs, mean, std, mf_mean, mf_std)
+                                 ctx["nx"], cfg.num_threads, 1, cfg.num_runs, mean, std, mf_mean, mf_std,
+                                 stencils=("cloudsc2_nl_saturation",) if args.fused else ("saturation", "cloudsc2_nl"))
     if cfg.enable_validation:
         ref_file = os.path.join(DATA_DIR, f"reference_{cfg.precision}.h5")
         print("\n== Validation:")

@@ -9,6 +9,17 @@ from typing import Any, Dict, Optional, Sequence, Tuple
 # Floating-point work per column used for the MFLOPS figure: the build's own count of the NL scheme
 # (~1e3 fp64 operation-equivalents per level-point x 137 levels), NOT an upstream value.
 FLOPS_PER_COLUMN = 1.0e3 * 137
+# Algorithmic HBM words per column (each input read once, each output written once; SURVEY.md 8a/8d, nz = 137)
+WORDS_PER_COLUMN = {"saturation": 411, "state_increment": 4416, "perturbed_state": 6624, "cloudsc2_nl": 3567,
+                    "cloudsc2_nl_saturation": 3567, "cloudsc2_nl_perturbed": 5760, "cloudsc2_tl": 7134,
+                    "cloudsc2_ad": 7134}
+HBM_PEAK_GBS = 8000.0   # MI355X spec peak the roofline columns are quoted against
+_WORD = {"double": 8, "single": 4}
+
+
+def algorithmic_gbs(stencils: Sequence[str], precision: str, num_cols: int, ms: float) -> float:
+    words = sum(WORDS_PER_COLUMN.get(s, 0) for s in stencils)
+    return words * _WORD.get(precision, 8) * num_cols / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
 
 
 def print_performance(num_cols: int, runtimes_ms: Sequence[float]) -> Tuple[float, float, float, float]:
@@ -32,11 +43,16 @@ def _append(path: str, header: Sequence[str], row: Sequence[Any]) -> None:
 
 
 def write_performance_to_csv(path, host, precision, variant, num_cols, num_threads, nproma, num_runs,
-                             runtime_mean, runtime_stddev, mflops_mean, mflops_stddev) -> None:
+                             runtime_mean, runtime_stddev, mflops_mean, mflops_stddev,
+                             stencils: Sequence[str] = ("saturation", "cloudsc2_nl")) -> None:
+    """The reference's columns (run_nonlinear.py:123-137) + algorithmic GB/s and % of the HBM roofline of the timed
+    region (`stencils` = what one run launches)."""
+    gbs = algorithmic_gbs(stencils, precision, num_cols, runtime_mean)
     _append(path, ["host", "precision", "variant", "num_cols", "num_threads", "nproma", "num_runs",
-                   "runtime_mean_ms", "runtime_stddev_ms", "mflops_mean", "mflops_stddev"],
+                   "runtime_mean_ms", "runtime_stddev_ms", "mflops_mean", "mflops_stddev", "columns_per_s",
+                   "algorithmic_GBs", "pct_hbm_roofline"],
             [host, precision, variant, num_cols, num_threads, nproma, num_runs, runtime_mean, runtime_stddev,
-             mflops_mean, mflops_stddev])
+             mflops_mean, mflops_stddev, num_cols / (runtime_mean * 1e-3), gbs, 100.0 * gbs / HBM_PEAK_GBS])
 
 
 def write_stencils_performance_to_csv(path, host, precision, variant, num_cols, num_threads, num_runs,
@@ -47,7 +63,9 @@ def write_stencils_performance_to_csv(path, host, precision, variant, num_cols, 
     for name, rec in (exec_info or {}).items():
         if isinstance(rec, dict) and any(p in name for p in key_patterns):
             calls = max(rec.get("ncalls", 0), 1)
+            mean_ms = 1e3 * rec.get("total_run_time", 0.0) / calls
+            gbs = algorithmic_gbs([name], precision, num_cols, mean_ms)
             _append(path, ["host", "precision", "variant", "num_cols", "num_threads", "num_runs", "stencil",
-                           "ncalls", "mean_ms"],
+                           "ncalls", "mean_ms", "algorithmic_GBs", "pct_hbm_roofline"],
                     [host, precision, variant, num_cols, num_threads, num_runs, name, rec.get("ncalls", 0),
-                     1e3 * rec.get("total_run_time", 0.0) / calls])
+                     mean_ms, gbs, 100.0 * gbs / HBM_PEAK_GBS])

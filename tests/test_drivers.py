@@ -169,6 +169,7 @@ def test_exec_info_and_stencil_csv_on_hip(gpu, tmp_path, capsys):
     rows = [r.split(",") for r in text.strip().splitlines()[1:]]
     for r in rows:
         assert int(r[7]) == 3 and 0.0 < float(r[8]) < 50.0          # 3 timed calls each, a sane mean in ms
+        assert float(r[9]) > 0.0 and 0.0 < float(r[10]) < 100.0     # algorithmic GB/s, % of the 8 TB/s roofline
 
 
 @pytest.mark.gpu

@@ -205,3 +205,43 @@ def test_fused_perturbation_variant_equals_separate_calls(gpu):
     torch.cuda.synchronize()
     for n in NL_OUT:
         assert torch.equal(outs2["out_" + n], outs["out_" + n]), n   # x + f*x_i is one fma in both paths
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("nz", [137, 5, 3, 2])
+def test_lds_ring_and_register_prefetch_paths_agree(gpu, dtype, nz):
+    """cloudsc2_nl has two load paths (csrc/cloudsc2_nl.hip): the LDS-DMA ring (whole waves, 16-byte aligned rows) and
+    the register prefetch (everything else).  The same 320 columns presented (a) as aligned contiguous storages and
+    (b) as a window that starts at column 1 of wider storages (misaligned rows -> register path) must agree 100x
+    tighter than the HIP-vs-oracle tolerance (the two kernels inline the same level function, but fma contraction may
+    differ between the two contexts), and both must match the oracle.  nz = 2 is below the ring depth (register path
+    both times)."""
+    import torch
+
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd import storage
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.stencils import compile_stencil
+
+    nx = 320
+    ext = externals(LEVAPLS2=True) if nz == 137 else externals()
+    fields, eta, dt = nl_case(nx, nz=nz, dtype=dtype, seed=3)
+    want = run_oracle_nl(fields, eta, dt, ext)
+    nl = compile_stencil("cloudsc2_nl", ext)
+    eta_d = torch.as_tensor(eta, device=gpu)
+    com = dict(in_eta=eta_d, dt=dt, origin=(0, 0, 0), domain=(nx, 1, nz + 1), validate_args=True, exec_info=None)
+    aligned = to_device(fields, gpu)
+    out_a = {"out_" + n: storage.zeros(nx, nz, dtype, gpu) for n in NL_OUT}
+    nl(**aligned, **out_a, **com)
+    wide = {k: torch.zeros((nz + 1, nx + 3), dtype=storage.torch_dtype(dtype), device=gpu) for k in fields}
+    for k, v in fields.items():
+        wide[k][:, 1:nx + 1] = torch.as_tensor(v, device=gpu)
+    shifted = {k: storage.logical_view(v[:, 1:nx + 1]) for k, v in wide.items()}
+    out_w = {"out_" + n: torch.zeros((nz + 1, nx + 3), dtype=storage.torch_dtype(dtype), device=gpu) for n in NL_OUT}
+    nl(**shifted, **{k: storage.logical_view(v[:, 1:nx + 1]) for k, v in out_w.items()}, **com)
+    torch.cuda.synchronize()
+    for n in NL_OUT:
+        a = storage.klayout(out_a["out_" + n]).cpu().numpy()
+        w = out_w["out_" + n][:, 1:nx + 1].cpu().numpy()
+        nlev = nz + 1 if n.startswith("f") else nz
+        assert_close(f"ring vs register out_{n}[nz={nz}]", a[:nlev], w[:nlev], dtype, rtol_mul=1e-2)
+        assert_close(f"ring out_{n}[nz={nz}]", a[:nlev], want[n][:nlev], dtype)
+        assert (out_w["out_" + n][:, 0] == 0).all() and (out_w["out_" + n][:, nx + 1:] == 0).all()  # window respected

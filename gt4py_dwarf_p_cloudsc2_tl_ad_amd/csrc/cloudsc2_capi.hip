@@ -9,7 +9,7 @@
 namespace cs2 {
 template <typename T>
 int launch_nl(const Cloudsc2Params&, int, int, int64_t, const T* const*, const T*, T* const*, double, hipStream_t,
-              const T* const*, double, T*);
+              const T* const*, double, T*, double*);
 template <typename T>
 int launch_tl(const Cloudsc2Params&, int, int, int64_t, const T* const*, const T* const*, const T*, T* const*,
               T* const*, double, hipStream_t);
@@ -70,7 +70,7 @@ int nl_impl(const char* fn, const Cloudsc2Params* p, int32_t nx, int32_t nz, int
     if (!(dt > 0.0)) return fail(CLOUDSC2_E_ARG, "%s: dt=%g must be > 0", fn, dt);
     if (nx == 0) return CLOUDSC2_OK;
     return launched(fn, cs2::launch_nl<T>(*p, nx, nz, ls, in, eta, out, dt, static_cast<hipStream_t>(stream), nullptr,
-                                          0.0, nullptr));
+                                          0.0, nullptr, nullptr));
 }
 
 // Fused variants of cloudsc2_nl (build extensions): exactly one of `qsat_out` / `in_i` is non-NULL.
@@ -93,7 +93,28 @@ int nl_fused_impl(const char* fn, const Cloudsc2Params* p, int32_t nx, int32_t n
     if (!(dt > 0.0)) return fail(CLOUDSC2_E_ARG, "%s: dt=%g must be > 0", fn, dt);
     if (nx == 0) return CLOUDSC2_OK;
     return launched(fn, cs2::launch_nl<T>(*p, nx, nz, ls, in, eta, out, dt, static_cast<hipStream_t>(stream), in_i, pf,
-                                          qsat_out));
+                                          qsat_out, nullptr));
+}
+
+// Perturbed NL run + Taylor-test reduction (build extension): see include/cloudsc2_hip.h.
+template <typename T>
+int nl_taylor_impl(const char* fn, const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls, const T* const* in,
+                   const T* const* in_i, double pf, const T* eta, const T* const* ref_out, double* partials, double dt,
+                   void* stream) {
+    if (int rc = check_common(fn, p, nx, nz, ls)) return rc;
+    if (int rc = check_ptrs(fn, "in", in, NL_NUM_IN)) return rc;
+    if (int rc = check_ptrs(fn, "in_i", in_i, NL_NUM_IN)) return rc;
+    if (int rc = check_ptrs(fn, "ref_out", ref_out, NL_NUM_OUT)) return rc;
+    if (!eta) return fail(CLOUDSC2_E_ARG, "%s: eta is NULL", fn);
+    if (!partials) return fail(CLOUDSC2_E_ARG, "%s: partials is NULL", fn);
+    if (p->ICALL != 0) return fail(CLOUDSC2_E_UNSUPPORTED, "%s: ICALL=%d unsupported", fn, p->ICALL);
+    if (!(dt > 0.0)) return fail(CLOUDSC2_E_ARG, "%s: dt=%g must be > 0", fn, dt);
+    if (nx == 0) return CLOUDSC2_OK;
+    // the kernel only READS the reference outputs; the launcher's pointer pack is the mutable one
+    T* refs[NL_NUM_OUT];
+    for (int i = 0; i < NL_NUM_OUT; ++i) refs[i] = const_cast<T*>(ref_out[i]);
+    return launched(fn, cs2::launch_nl<T>(*p, nx, nz, ls, in, eta, refs, dt, static_cast<hipStream_t>(stream), in_i, pf,
+                                          nullptr, partials));
 }
 
 template <typename T>
@@ -191,6 +212,17 @@ int32_t cloudsc2_nl_fused_f32(const Cloudsc2Params* p, int32_t nx, int32_t nz, i
                               const float* const* in_i, double pf, float* qsat_out, const float* eta,
                               float* const* out, double dt, void* stream) {
     return nl_fused_impl<float>("cloudsc2_nl_fused_f32", p, nx, nz, ls, in, in_i, pf, qsat_out, eta, out, dt, stream);
+}
+int32_t cloudsc2_nl_taylor_blocks(int32_t nx) { return nx <= 0 ? 0 : (nx + cs2::kColBlock - 1) / cs2::kColBlock; }
+int32_t cloudsc2_nl_taylor_f64(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls, const double* const* in,
+                               const double* const* in_i, double pf, const double* eta, const double* const* ref_out,
+                               double* partials, double dt, void* stream) {
+    return nl_taylor_impl<double>("cloudsc2_nl_taylor_f64", p, nx, nz, ls, in, in_i, pf, eta, ref_out, partials, dt, stream);
+}
+int32_t cloudsc2_nl_taylor_f32(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls, const float* const* in,
+                               const float* const* in_i, double pf, const float* eta, const float* const* ref_out,
+                               double* partials, double dt, void* stream) {
+    return nl_taylor_impl<float>("cloudsc2_nl_taylor_f32", p, nx, nz, ls, in, in_i, pf, eta, ref_out, partials, dt, stream);
 }
 int32_t cloudsc2_tl_f64(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls, const double* const* in,
                         const double* const* in_i, const double* eta, double* const* out, double* const* out_i,

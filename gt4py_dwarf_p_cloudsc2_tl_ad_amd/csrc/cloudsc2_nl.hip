@@ -381,10 +381,15 @@ __device__ __forceinline__ T nl_trpaus(const T* __restrict__ pt, const T* __rest
 //   2  `perturbed_state` fused in: every input is read as in + pf * in_i
 //      (common/_stencils/perturbed_state.py:75-91) - the Taylor test's ten perturbed NL runs no longer
 //      write and re-read a perturbed copy of the 16-field state.
+//   3  = 2 + the Taylor test's reduction in the epilogue: nothing is stored; `out` holds the UNPERTURBED NL
+//      outputs (read-only) and every workgroup writes the 10 sums  sum_{k, col in block}(NL(x + pf x_i) - NL(x))
+//      (tangent_linear/validation.py:239-249) to partials[block][field] in double precision.  One partial per
+//      workgroup, summed by the caller: deterministic, no atomics.
 template <typename T, bool EVAP, bool LIN, bool PINK, int FUSE>
 __global__ void __launch_bounds__(kColBlock, (sizeof(T) == 4 ? CS2_F32_WAVES : 1))
 nl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, NL_NUM_IN> in, const T* __restrict__ eta,
-          MPtrs<T, NL_NUM_OUT> out, T dt, CPtrs<T, NL_NUM_IN> in_i, T pf, T* __restrict__ qsat_out) {
+          MPtrs<T, NL_NUM_OUT> out, T dt, CPtrs<T, NL_NUM_IN> in_i, T pf, T* __restrict__ qsat_out,
+          double* __restrict__ partials) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     T* s_eta = reinterpret_cast<T*>(smem_raw);
     T* s_scalm = s_eta + (nz + 1);
@@ -430,7 +435,7 @@ nl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
     c.aph_k = ldg(in.p[NL_IN_APH], colb);
     const T aph_s = EVAP ? ldg(in.p[NL_IN_APH], uint32_t(nz) * lsb + colb) : T(1.0);
 
-    if (live) {
+    if (live && FUSE != 3) {
         // top half level: no flux enters the column (:392-394; out_fpls*[0] written as 0, the
         // value the reference relies on from zero-initialised storage - SURVEY.md App. B Q2)
         stg(out.p[NL_OUT_FPLSL], colb, T(0.0));
@@ -444,15 +449,17 @@ nl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
     // hide behind this wave's own work).
     constexpr int PD = CS2_NL_PREFETCH;
     NLIn<T> buf[PD + 1];
-    NLIn<T> bufi[FUSE == 2 ? PD + 1 : 1];
+    constexpr bool PERT = FUSE == 2 || FUSE == 3;
+    NLIn<T> bufi[PERT ? PD + 1 : 1];
 #pragma unroll
     for (int j = 0; j < PD; ++j) {
         const uint32_t oj = colb + uint32_t(j < nz ? j : 0) * lsb;
         buf[j] = nl_load<T, FUSE == 1>(in, lsb, oj);
-        if constexpr (FUSE == 2) bufi[j] = nl_load<T, false>(in_i, lsb, oj);
+        if constexpr (PERT) bufi[j] = nl_load<T, false>(in_i, lsb, oj);
     }
     buf[PD] = buf[0];
-    if constexpr (FUSE == 2) bufi[PD] = bufi[0];
+    if constexpr (PERT) bufi[PD] = bufi[0];
+    double acc[FUSE == 3 ? NL_NUM_OUT : 1] = {};
     uint32_t o = colb;  // byte offset of (level k, column)
     for (int k0 = 0; k0 < nz; k0 += PD + 1) {
 #pragma unroll
@@ -461,19 +468,60 @@ nl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
             if (k < nz) {
                 if (k + PD < nz) {
                     buf[(j + PD) % (PD + 1)] = nl_load<T, FUSE == 1>(in, lsb, o + uint32_t(PD) * lsb);
-                    if constexpr (FUSE == 2)
+                    if constexpr (PERT)
                         bufi[(j + PD) % (PD + 1)] = nl_load<T, false>(in_i, lsb, o + uint32_t(PD) * lsb);
                 }
                 NLIn<T> x = buf[j];
-                if constexpr (FUSE == 2) x = nl_perturb<T>(x, bufi[j], pf);
+                if constexpr (PERT) x = nl_perturb<T>(x, bufi[j], pf);
+                T ref[FUSE == 3 ? NL_NUM_OUT : 1];
+                if constexpr (FUSE == 3) {   // requested before the physics, consumed after it
+#pragma unroll
+                    for (int f = 0; f < NL_NUM_OUT; ++f) {
+                        const bool half = f == NL_OUT_FPLSL || f == NL_OUT_FPLSN || f == NL_OUT_FHPSL || f == NL_OUT_FHPSN;
+                        ref[f] = ldg(const_cast<const T*>(out.p[f]), half ? o + lsb : o);
+                    }
+                }
                 if constexpr (FUSE == 1) {
                     x.qsat = nl_saturation<T>(e, xk, x.ap, x.t);
                     if (live) stg(qsat_out, o, x.qsat);
                 }
                 const NLOut<T> r = nl_level<T, EVAP, LIN>(e, kc, xk, x, s_eta[k], s_scalm[k], crh, dt, aph_s, c);
-                if (live) nl_store<T>(out, e, lsb, o, r);
+                if constexpr (FUSE == 3) {
+                    if (live) {
+                        acc[NL_OUT_CLC] += double(r.clc - ref[NL_OUT_CLC]);
+                        acc[NL_OUT_COVPTOT] += double(r.covptot - ref[NL_OUT_COVPTOT]);
+                        acc[NL_OUT_TND_Q] += double(r.tnd_q - ref[NL_OUT_TND_Q]);
+                        acc[NL_OUT_TND_T] += double(r.tnd_t - ref[NL_OUT_TND_T]);
+                        acc[NL_OUT_TND_QL] += double(r.tnd_ql - ref[NL_OUT_TND_QL]);
+                        acc[NL_OUT_TND_QI] += double(r.tnd_qi - ref[NL_OUT_TND_QI]);
+                        acc[NL_OUT_FPLSL] += double(r.rfln - ref[NL_OUT_FPLSL]);
+                        acc[NL_OUT_FPLSN] += double(r.sfln - ref[NL_OUT_FPLSN]);
+                        acc[NL_OUT_FHPSL] += double(-r.rfln * e.RLVTT - ref[NL_OUT_FHPSL]);
+                        acc[NL_OUT_FHPSN] += double(-r.sfln * e.RLSTT - ref[NL_OUT_FHPSN]);
+                    }
+                } else {
+                    if (live) nl_store<T>(out, e, lsb, o, r);
+                }
                 o += lsb;
             }
+        }
+    }
+    if constexpr (FUSE == 3) {
+        // workgroup reduction of the 10 sums: wave shuffle, then one LDS hop (the level table is no longer needed)
+        __shared__ double s_red[kColBlock / 64][NL_NUM_OUT];
+#pragma unroll
+        for (int f = 0; f < NL_NUM_OUT; ++f) {
+            double v = acc[f];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6][f] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < NL_NUM_OUT) {
+            double v = 0.0;
+#pragma unroll
+            for (int w = 0; w < kColBlock / 64; ++w) v += s_red[w][threadIdx.x];
+            partials[size_t(blockIdx.x) * NL_NUM_OUT + threadIdx.x] = v;
         }
     }
 }
@@ -687,7 +735,8 @@ nl_ring_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtr
 
 template <typename T>
 int launch_nl(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* const* in, const T* eta, T* const* out,
-              double dt, hipStream_t stream, const T* const* in_i = nullptr, double pf = 0.0, T* qsat_out = nullptr) {
+              double dt, hipStream_t stream, const T* const* in_i = nullptr, double pf = 0.0, T* qsat_out = nullptr,
+              double* partials = nullptr) {
     const Ext<T> e = make_ext<T>(p);
     CPtrs<T, NL_NUM_IN> ci, cii;
     MPtrs<T, NL_NUM_OUT> co;
@@ -705,11 +754,11 @@ int launch_nl(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
     const NLK<T> kc = make_nlk<T>(p, dt, evap);
     const ExpK<T> xk = make_expk<T>();
     if (!fits_u32_offsets<T>(nz, ls)) return -2;
-    const int fuse = qsat_out ? 1 : (in_i ? 2 : 0);
+    const int fuse = qsat_out ? 1 : (in_i ? (partials ? 3 : 2) : 0);
     if (fuse == 1 && !p.LPHYLIN) return -2;   // only the LPHYLIN form of `saturation` is fused
 #define CS2_NL_LAUNCH(EV, LN, FU)                                                                                 \
     hipLaunchKernelGGL((nl_kernel<T, EV, LN, sizeof(T) == 8, FU>), grid, block, smem, stream, e, kc, xk, nx, nz, \
-                       ls, ci, eta, co, tdt, cii, tpf, qsat_out)
+                       ls, ci, eta, co, tdt, cii, tpf, qsat_out, partials)
 #define CS2_NL_FLAGS(FU)                                   \
     do {                                                   \
         if (evap && lin) CS2_NL_LAUNCH(true, true, FU);    \
@@ -747,15 +796,16 @@ int launch_nl(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
 #endif
     if (fuse == 0) CS2_NL_FLAGS(0);
     else if (fuse == 1) CS2_NL_FLAGS(1);
-    else CS2_NL_FLAGS(2);
+    else if (fuse == 2) CS2_NL_FLAGS(2);
+    else CS2_NL_FLAGS(3);
 #undef CS2_NL_FLAGS
 #undef CS2_NL_LAUNCH
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 template int launch_nl<double>(const Cloudsc2Params&, int, int, int64_t, const double* const*, const double*,
-                               double* const*, double, hipStream_t, const double* const*, double, double*);
+                               double* const*, double, hipStream_t, const double* const*, double, double*, double*);
 template int launch_nl<float>(const Cloudsc2Params&, int, int, int64_t, const float* const*, const float*,
-                              float* const*, double, hipStream_t, const float* const*, double, float*);
+                              float* const*, double, hipStream_t, const float* const*, double, float*, double*);
 
 }  // namespace cs2

@@ -16,7 +16,7 @@ def core(args):
                     lphylin=True, ldrain1d=False, yoethf_params=p["yoethf"], yomcst_params=p["yomcst"],
                     yrecldp_params=p["yrecldp"], yrephli_params=p["yrephli"], yrncl_params=p["yrncl"],
                     yrphnc_params=p["yrphnc"], enable_checks=cfg.sympl_enable_checks, gt4py_config=cfg.gt4py_config,
-                    fused=args.fused)
+                    fused=args.fused, fused_norms=args.fused_norms)
     norms = tt.run(ctx["state"], ctx["dt"])                  # warm-up; these norms are the validated ones
     runtimes = []
     for _ in range(cfg.num_runs):
@@ -36,6 +36,8 @@ def main(argv=None):
     add_common_options(ap)
     ap.add_argument("--fused", action="store_true",
                     help="apply the perturbation inside the NL kernel (build extension cloudsc2_nl_perturbed)")
+    ap.add_argument("--fused-norms", action="store_true",
+                    help="--fused + the ten difference sums formed in the kernel epilogue (cloudsc2_nl_taylor)")
     args = ap.parse_args(argv)
     init_distributed_from_env()
     return core(args)

@@ -7,6 +7,9 @@ observable contract).  Differences, all on the measurement side:
   * every reduction runs on the GPU (the reference copies ~40 fields to the host per call);
   * with `torch.distributed` initialised the Taylor sums are all-reduced (SUM) and the symmetry
     maximum all-reduced (MAX) over the column shards - the only communication of the whole path;
+  * `TaylorTest(..., fused=True)` applies the perturbation inside the NL kernel's loads (stencil `cloudsc2_nl_perturbed`);
+    `fused_norms=True` additionally forms the ten sums of NL(x + f x_i) - NL(x) in that kernel's epilogue (stencil
+    `cloudsc2_nl_taylor`: no perturbed outputs are stored, no separate difference / sum kernels run);
   * `SymmetryTest(..., ad_traj_fix=True)` selects the AD kernel variant whose freezing tests match
     NL/TL (include/cloudsc2_hip.h, `AD_TRAJ_FIX`); default False = the reference's literal behaviour.
 """
@@ -66,9 +69,20 @@ def taylor_verdict(norms: Sequence[float]) -> Tuple[bool, str]:
 class TaylorTest:
     def __init__(self, computational_grid, factor1: float, factor2s: Tuple[float, ...], kflag: int, lphylin: bool,
                  ldrain1d: bool, yoethf_params, yomcst_params, yrecldp_params, yrephli_params, yrncl_params,
-                 yrphnc_params, *, enable_checks: bool = True, gt4py_config, fused: bool = False) -> None:
+                 yrphnc_params, *, enable_checks: bool = True, gt4py_config, fused: bool = False,
+                 fused_norms: bool = False) -> None:
         self.f1, self.f2s = factor1, tuple(factor2s)
-        self.fused = fused
+        self.fused = fused or fused_norms
+        self.fused_norms = fused_norms
+        self._taylor = None
+        if fused_norms:
+            from .physics import _externals
+            from .stencils import compile_stencil
+
+            self._taylor = compile_stencil("cloudsc2_nl_taylor", _externals(
+                yoethf_params, yomcst_params, yrecldp_params, yrephli_params, yrphnc_params, ICALL=0, LPHYLIN=lphylin,
+                LDRAIN1D=ldrain1d, ZEPS1=1e-12, ZEPS2=1e-10, ZQMAX=0.5, ZSCAL=0.9))
+            self._gt4py_config = gt4py_config
         # no regularization in the Taylor test (validation.py:84-85)
         yrncl = dict(yrncl_params.dict() if hasattr(yrncl_params, "dict") else yrncl_params)
         yrncl["LREGCL"] = False
@@ -79,7 +93,9 @@ class TaylorTest:
         self.cloudsc2_tl = Cloudsc2TL(computational_grid, lphylin, ldrain1d, yoethf_params, yomcst_params,
                                       yrecldp_params, yrephli_params, yrncl, yrphnc_params, **kw)
         self.state_increment = StateIncrement(computational_grid, factor1, **kw)
-        if fused:
+        if self.fused_norms:
+            self.perturbed_states = [None] * len(self.f2s)
+        elif fused:
             # build extension: perturbation applied inside the NL kernel's loads (no perturbed copy of the state)
             self.perturbed_nls = [Cloudsc2NLPerturbed(computational_grid, f2, lphylin, ldrain1d, yoethf_params,
                                                       yomcst_params, yrecldp_params, yrephli_params, yrphnc_params,
@@ -117,6 +133,11 @@ class TaylorTest:
         sums_tl = _allreduce(sums_tl, "sum")
         norms = np.zeros(len(self.f2s))
         for i, perturbed_state in enumerate(self.perturbed_states):
+            if self.fused_norms:
+                with timing("run"):
+                    diffs = _allreduce(self._fused_diffs(state, timestep, self.f2s[i], names), "sum")
+                norms[i] = self._norm(self.f2s[i], diffs.cpu().numpy(), sums_tl.cpu().numpy())
+                continue
             with timing("run"):
                 if self.fused:
                     self.tends_nl_p, self.diags_nl_p = self.perturbed_nls[i](
@@ -133,6 +154,27 @@ class TaylorTest:
                 diffs = _allreduce(diffs, "sum")
                 norms[i] = self._norm(self.f2s[i], diffs.cpu().numpy(), sums_tl.cpu().numpy())
         return norms
+
+    def _fused_diffs(self, state, timestep: timedelta, f2: float, names) -> torch.Tensor:
+        """sum(NL(x + f2 x_i) - NL(x)) per output field, formed in the epilogue of ONE kernel launch."""
+        from .stencils import NL_IN, NL_OUT, taylor_blocks
+
+        any_f = state["f_ap"].data
+        nx, nz = any_f.shape[0], any_f.shape[2] - 1
+        part = torch.empty((taylor_blocks(nx), len(NL_OUT)), dtype=torch.float64, device=any_f.device)
+        kw = {}
+        for n in NL_IN:
+            kw["in_" + n] = state["f_" + n].data
+            kw["in_" + n + "_i"] = state["f_" + n + "_i"].data
+        for n in NL_OUT:   # unperturbed outputs: tendencies are published as f_q / f_qi / f_ql / f_t
+            kw["ref_" + n] = (self.tends_nl["f_" + n[len("tnd_"):]] if n.startswith("tnd_") else self.diags_nl["f_" + n]).data
+        cfg = self._gt4py_config
+        self._taylor(**kw, in_eta=state["f_eta"].data if hasattr(state["f_eta"], "data") else state["f_eta"],
+                     out_partials=part, f=f2, dt=float(timestep.total_seconds()), origin=(0, 0, 0),
+                     domain=(nx, 1, nz + 1), validate_args=cfg.validate_args, exec_info=cfg.exec_info)
+        sums = part.sum(dim=0)                       # fixed block order: deterministic
+        idx = [NL_OUT.index(("tnd_" + n[2:]) if k == "tends" else n[2:]) for k, n in names]
+        return sums[idx]
 
     @staticmethod
     def _norm(f2: float, diffs: np.ndarray, sums_tl: np.ndarray) -> float:

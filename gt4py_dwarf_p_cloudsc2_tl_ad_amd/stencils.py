@@ -209,6 +209,45 @@ class Cloudsc2NLPerturbedStencil(HipStencil):
             _ptrs(fields, ["out_" + n for n in NL_OUT]), scalar, stream)
 
 
+class Cloudsc2NLTaylorStencil(HipStencil):
+    """BUILD EXTENSION `cloudsc2_nl_taylor`: perturbed NL run + the Taylor test's reduction in one launch (C ABI
+    `cloudsc2_nl_taylor_*`).  Fields: the 16 `in_*`, the 16 `in_*_i`, the 10 unperturbed outputs `ref_*` (read-only);
+    scalar `f`; `out_partials`: contiguous float64 tensor of shape (taylor_blocks(nx), 10) that receives, per
+    workgroup, sum(NL(in + f in_i) - ref) for the 10 outputs in NL_OUT order.  Nothing else is written."""
+
+    name = "cloudsc2_nl_taylor"
+
+    def __call__(self, **kwargs: Any) -> None:
+        if "f" not in kwargs or "out_partials" not in kwargs:
+            raise TypeError(f"{self.name}: missing argument 'f' / 'out_partials'")
+        self._pf = float(kwargs.pop("f"))
+        self._partials = kwargs.pop("out_partials")
+        super().__call__(**kwargs)
+
+    def _field_names(self):
+        return (tuple("in_" + n for n in NL_IN) + tuple("in_" + n + "_i" for n in NL_IN)
+                + tuple("ref_" + n for n in NL_OUT))
+
+    def _launch(self, fields, eta, scalar, nx, nz, ls, sfx, stream):
+        if eta is None:
+            raise TypeError(f"{self.name}: missing field argument 'in_eta'")
+        part = self._partials
+        need = taylor_blocks(nx)
+        if (not isinstance(part, torch.Tensor) or part.dtype != torch.float64 or not part.is_contiguous()
+                or part.device != fields["in_ap"].device or part.numel() < need * len(NL_OUT)):
+            raise ValueError(f"{self.name}: out_partials must be a contiguous float64 device tensor with >= "
+                             f"{need} x {len(NL_OUT)} elements")
+        return self._fn("nl_taylor", sfx)(
+            ctypes.byref(self.params), nx, nz, ls, _ptrs(fields, ["in_" + n for n in NL_IN]),
+            _ptrs(fields, ["in_" + n + "_i" for n in NL_IN]), self._pf, eta.data_ptr(),
+            _ptrs(fields, ["ref_" + n for n in NL_OUT]), part.data_ptr(), scalar, stream)
+
+
+def taylor_blocks(nx: int) -> int:
+    """Number of per-workgroup partial rows `cloudsc2_nl_taylor` writes for nx columns."""
+    return int(_lib.load().cloudsc2_nl_taylor_blocks(int(nx)))
+
+
 class Cloudsc2TLStencil(HipStencil):
     """`cloudsc2_tl` - tangent_linear/_stencils/cloudsc2.py:23-90 (signature), :124-774 (body)."""
 
@@ -305,6 +344,7 @@ STENCILS: Dict[str, type] = {
     "cloudsc2_nl": Cloudsc2NLStencil,
     "cloudsc2_nl_saturation": Cloudsc2NLSaturationStencil,   # build extension (fused)
     "cloudsc2_nl_perturbed": Cloudsc2NLPerturbedStencil,     # build extension (fused)
+    "cloudsc2_nl_taylor": Cloudsc2NLTaylorStencil,           # build extension (fused + reduction)
     "cloudsc2_tl": Cloudsc2TLStencil,
     "cloudsc2_ad": Cloudsc2ADStencil,
     "saturation": SaturationStencil,

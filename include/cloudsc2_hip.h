@@ -97,6 +97,21 @@ int32_t cloudsc2_nl_fused_f32(const Cloudsc2Params* p, int32_t nx, int32_t nz, i
                               const float* const* in, const float* const* in_i, double pf, float* qsat_out,
                               const float* eta, float* const* out, double dt, void* stream);
 
+/* ---- perturbed NL run + Taylor-test reduction (BUILD EXTENSION, SURVEY.md 8f rank 1, third item).
+ * Replaces, per step size, perturbed_state + cloudsc2_nl + the ten field differences and sums of
+ * TaylorTest.run / get_field_norm (tangent_linear/validation.py:166-176, :239-249): NL is evaluated on in + pf * in_i,
+ * nothing is stored, and workgroup b writes  partials[b * NL_NUM_OUT + f] = sum over its columns and all levels of
+ * (NL(in + pf in_i) - ref_out)[f]  in double precision (f in NL_OUT_* order; ref_out = the unperturbed NL outputs,
+ * read-only).  `partials` is a DEVICE array of cloudsc2_nl_taylor_blocks(nx) * NL_NUM_OUT doubles; the caller adds
+ * the blocks (fixed order: deterministic). */
+int32_t cloudsc2_nl_taylor_blocks(int32_t nx);
+int32_t cloudsc2_nl_taylor_f64(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t lev_stride,
+                               const double* const* in, const double* const* in_i, double pf, const double* eta,
+                               const double* const* ref_out, double* partials, double dt, void* stream);
+int32_t cloudsc2_nl_taylor_f32(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t lev_stride,
+                               const float* const* in, const float* const* in_i, double pf, const float* eta,
+                               const float* const* ref_out, double* partials, double dt, void* stream);
+
 /* ---- saturation : common/_stencils/saturation.py:23-42, called at common/saturation.py:67-76
  * (domain nx x 1 x nz: level nz of out_qsat is not written) */
 int32_t cloudsc2_saturation_f64(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t lev_stride,

@@ -188,3 +188,19 @@ def test_fused_driver_variants_match_the_unfused_ones(gpu, capsys):
     t1 = run_taylor_test.main(["--backend", "hip", "--num-cols", "4096", "--disable-validation", "--fused"])
     np.testing.assert_allclose(t1["norms"], t0["norms"], rtol=1e-12)
     capsys.readouterr()
+
+
+@pytest.mark.gpu
+def test_taylor_driver_with_fused_norms(gpu, capsys):
+    """`--fused-norms`: the whole perturbation step (perturb, NL, difference, sums) is one kernel launch; the verdict
+    and the norms are those of the unfused harness (summation order differs, so compare the error |1 - norm| loosely)."""
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.drivers import run_taylor_test
+
+    t0 = run_taylor_test.main(["--backend", "hip", "--num-cols", "4096", "--disable-validation"])
+    t1 = run_taylor_test.main(["--backend", "hip", "--num-cols", "4096", "--disable-validation", "--fused-norms"])
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.harness import taylor_verdict
+
+    assert taylor_verdict(t0["norms"])[0] and taylor_verdict(t1["norms"])[0]
+    np.testing.assert_allclose(t1["norms"][:6], t0["norms"][:6], rtol=1e-7)
+    np.testing.assert_allclose(t1["norms"], t0["norms"], rtol=1e-2)
+    capsys.readouterr()

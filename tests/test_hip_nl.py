@@ -245,3 +245,40 @@ def test_lds_ring_and_register_prefetch_paths_agree(gpu, dtype, nz):
         assert_close(f"ring vs register out_{n}[nz={nz}]", a[:nlev], w[:nlev], dtype, rtol_mul=1e-2)
         assert_close(f"ring out_{n}[nz={nz}]", a[:nlev], want[n][:nlev], dtype)
         assert (out_w["out_" + n][:, 0] == 0).all() and (out_w["out_" + n][:, nx + 1:] == 0).all()  # window respected
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_taylor_reduction_variant_matches_separate_calls(gpu, dtype):
+    """`cloudsc2_nl_taylor` (build extension): perturbed NL run with the Taylor test's ten sums formed in the kernel
+    epilogue == perturbed_state -> cloudsc2_nl -> (out_p - out).sum() done with separate kernels; the reference
+    outputs are left untouched.  Sums differ only by summation order."""
+    import torch
+
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd import storage
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.stencils import compile_stencil, taylor_blocks
+
+    nx, nz, f2 = 777, 137, 1e-2
+    ext = externals()
+    fields, eta, dt = nl_case(nx, dtype=dtype)
+    dev = to_device(fields, gpu)
+    inc = {k + "_i": (0.01 * v).clone() for k, v in dev.items()}
+    eta_d = torch.as_tensor(eta, device=gpu)
+    com = dict(in_eta=eta_d, dt=dt, origin=(0, 0, 0), domain=(nx, 1, nz + 1), validate_args=True, exec_info=None)
+    ref = {"out_" + n: storage.zeros(nx, nz, dtype, gpu) for n in NL_OUT}
+    compile_stencil("cloudsc2_nl", ext)(**dev, **ref, **com)
+    pert = {"out_" + n: storage.zeros(nx, nz, dtype, gpu) for n in NL_OUT}
+    compile_stencil("cloudsc2_nl_perturbed", ext)(**dev, **inc, **pert, f=f2, **com)
+    want = torch.stack([(pert["out_" + n].double() - ref["out_" + n].double()).sum() for n in NL_OUT]).cpu().numpy()
+    keep = {k: v.clone() for k, v in ref.items()}
+    part = torch.full((taylor_blocks(nx), len(NL_OUT)), float("nan"), dtype=torch.float64, device=gpu)
+    assert taylor_blocks(nx) == -(-nx // 256)
+    compile_stencil("cloudsc2_nl_taylor", ext)(**dev, **inc, **{"ref_" + n: ref["out_" + n] for n in NL_OUT},
+                                                out_partials=part, f=f2, **com)
+    torch.cuda.synchronize()
+    got = part.sum(dim=0).cpu().numpy()
+    for k in ref:
+        assert torch.equal(ref[k], keep[k]), k
+    mag = torch.stack([(pert["out_" + n].double() - ref["out_" + n].double()).abs().sum() for n in NL_OUT]).cpu().numpy()
+    tol = 1e-12 if dtype == np.float64 else 1e-6
+    assert np.all(np.abs(got - want) <= tol * mag + 1e-300), (got, want)
+    assert np.abs(want).max() > 0

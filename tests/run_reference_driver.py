@@ -7,6 +7,8 @@ import os
 import runpy
 import sys
 
+sys.dont_write_bytecode = True   # importing the reference package must not leave __pycache__ in the read-only checkout
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REFERENCE = os.environ.get("CLOUDSC2_REFERENCE", "/root/reference")
 

@@ -17,7 +17,8 @@ pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REFERENCE, "drive
 
 def _run(driver, *args):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "run_reference_driver.py"), driver, *args],
-                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+                       capture_output=True, text=True, timeout=900, cwd=ROOT,
+                       env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))   # nothing is written into /root/reference
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     return p.stdout
 

@@ -774,15 +774,18 @@ int launch_nl(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
         using G = RingGeom<T>;
         const size_t tab = (2 * size_t(nz + 1) * sizeof(T) + 1023) & ~size_t(1023);
         const size_t rsmem = tab + size_t(kColBlock / 64) * CS2_NL_RING * G::SLOT;
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return -1;
 #define CS2_NL_RING_LAUNCH(EV, LN)                                                                                   \
     do {                                                                                                             \
         auto kern = nl_ring_kernel<T, EV, LN, sizeof(T) == 8, CS2_NL_RING>;                                          \
-        static bool attr_set = false; /* > 64 KB of dynamic LDS needs the opt-in, once per instantiation */          \
-        if (!attr_set) {                                                                                             \
+        /* > 64 KB of dynamic LDS needs the opt-in: once per instantiation, device and size */                       \
+        static size_t attr_set[64] = {};                                                                             \
+        if (attr_set[dev & 63] < rsmem) {                                                                            \
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                     int(rsmem)) != hipSuccess)                                                       \
                 return -1;                                                                                           \
-            attr_set = true;                                                                                         \
+            attr_set[dev & 63] = rsmem;                                                                              \
         }                                                                                                            \
         hipLaunchKernelGGL(kern, grid, block, rsmem, stream, e, kc, xk, nx, nz, ls, ci, eta, co, tdt);               \
     } while (0)

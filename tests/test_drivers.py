@@ -204,3 +204,21 @@ def test_taylor_driver_with_fused_norms(gpu, capsys):
     np.testing.assert_allclose(t1["norms"][:6], t0["norms"][:6], rtol=1e-7)
     np.testing.assert_allclose(t1["norms"], t0["norms"], rtol=1e-2)
     capsys.readouterr()
+
+
+@pytest.mark.gpu
+def test_nonlinear_driver_with_hip_graph(gpu, capsys):
+    """`--graph`: the timed region replayed from a captured HIP graph gives the same fields as the eager loop."""
+    import torch
+
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.drivers import run_nonlinear
+
+    base = ["--backend", "hip", "--num-cols", "4096", "--num-runs", "3", "--disable-validation"]
+    a = run_nonlinear.main(base)
+    for extra in (["--graph"], ["--graph", "--fused"]):
+        b = run_nonlinear.main(base + extra)
+        assert len(b["runtimes_ms"]) == 3
+        for d in ("tends", "diags"):
+            for k, v in a[d].items():
+                assert torch.equal(v.data, b[d][k].data), (extra, k)
+    capsys.readouterr()

@@ -767,18 +767,30 @@ int launch_nl(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
         else CS2_NL_LAUNCH(false, false, FU);              \
     } while (0)
 #if CS2_NL_RING
-    // LDS-ring variant: whole waves, 16-byte aligned rows of every input field (the DMA moves 16 B per lane)
+    // LDS-ring variant: whole waves, 16-byte aligned rows of every input field (the DMA moves 16 B per lane).
+    // Ring depth by grid size (profiles/ab_nl.py, fp64, same box): with at most ~1.5 workgroups per CU the deep ring
+    // wins (32 768 columns: 244 us vs 259 us at depth 2 vs 299 us register prefetch; 98 304: 609 / 633 / 651 us); with
+    // more, LDS occupancy matters more than depth - depth 2 keeps two workgroups resident per CU (131 072 columns:
+    // 655 us vs 692 us at depth 3; 262 144: 1 286 vs 1 350 us).
     bool ring = fuse == 0 && nx % 64 == 0 && nz >= CS2_NL_RING && (ls * int64_t(sizeof(T))) % 16 == 0;
     for (int i = 0; i < NL_NUM_IN && ring; ++i) ring = reinterpret_cast<uintptr_t>(in[i]) % 16 == 0;
     if (ring) {
         using G = RingGeom<T>;
-        const size_t tab = (2 * size_t(nz + 1) * sizeof(T) + 1023) & ~size_t(1023);
-        const size_t rsmem = tab + size_t(kColBlock / 64) * CS2_NL_RING * G::SLOT;
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess) return -1;
-#define CS2_NL_RING_LAUNCH(EV, LN)                                                                                   \
+        static int cus[64] = {};
+        if (cus[dev & 63] == 0) {
+            int n = 0;
+            if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+            cus[dev & 63] = n;
+        }
+        const bool deep = int64_t(grid.x) * 2 <= int64_t(cus[dev & 63]) * 3;
+        const int depth = deep ? CS2_NL_RING : 2;
+        const size_t tab = (2 * size_t(nz + 1) * sizeof(T) + 1023) & ~size_t(1023);
+        const size_t rsmem = tab + size_t(kColBlock / 64) * depth * G::SLOT;
+#define CS2_NL_RING_LAUNCH(EV, LN, RD)                                                                               \
     do {                                                                                                             \
-        auto kern = nl_ring_kernel<T, EV, LN, sizeof(T) == 8, CS2_NL_RING>;                                          \
+        auto kern = nl_ring_kernel<T, EV, LN, sizeof(T) == 8, RD>;                                                   \
         /* > 64 KB of dynamic LDS needs the opt-in: once per instantiation, device and size */                       \
         static size_t attr_set[64] = {};                                                                             \
         if (attr_set[dev & 63] < rsmem) {                                                                            \
@@ -789,10 +801,16 @@ int launch_nl(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
         }                                                                                                            \
         hipLaunchKernelGGL(kern, grid, block, rsmem, stream, e, kc, xk, nx, nz, ls, ci, eta, co, tdt);               \
     } while (0)
-        if (evap && lin) CS2_NL_RING_LAUNCH(true, true);
-        else if (evap && !lin) CS2_NL_RING_LAUNCH(true, false);
-        else if (!evap && lin) CS2_NL_RING_LAUNCH(false, true);
-        else CS2_NL_RING_LAUNCH(false, false);
+#define CS2_NL_RING_FLAGS(RD)                                          \
+    do {                                                               \
+        if (evap && lin) CS2_NL_RING_LAUNCH(true, true, RD);           \
+        else if (evap && !lin) CS2_NL_RING_LAUNCH(true, false, RD);    \
+        else if (!evap && lin) CS2_NL_RING_LAUNCH(false, true, RD);    \
+        else CS2_NL_RING_LAUNCH(false, false, RD);                     \
+    } while (0)
+        if (deep) CS2_NL_RING_FLAGS(CS2_NL_RING);
+        else CS2_NL_RING_FLAGS(2);
+#undef CS2_NL_RING_FLAGS
 #undef CS2_NL_RING_LAUNCH
         return hipGetLastError() == hipSuccess ? 0 : -1;
     }

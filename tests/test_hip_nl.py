@@ -282,3 +282,41 @@ def test_taylor_reduction_variant_matches_separate_calls(gpu, dtype):
     tol = 1e-12 if dtype == np.float64 else 1e-6
     assert np.all(np.abs(got - want) <= tol * mag + 1e-300), (got, want)
     assert np.abs(want).max() > 0
+
+
+def test_large_grid_takes_the_shallow_ring(gpu):
+    """More than ~1.5 workgroups per CU: launch_nl selects ring depth 2 (two workgroups resident per CU).  131 072
+    columns through that path against (a) the same columns run as a small separate call (deep ring) and (b) the oracle."""
+    import torch
+
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd import storage
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.stencils import compile_stencil
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.synthetic import eta_levels, make_state
+
+    nx, nz = 131072, 137
+    ext = externals()
+    s = make_state(nx, nz, device=gpu)
+    eta = torch.as_tensor(eta_levels(nz), device=gpu)
+    ins = {"in_" + k[2:]: storage.logical_view(v) for k, v in s.items()}
+    qsat = storage.zeros(nx, nz, np.float64, gpu)
+    compile_stencil("saturation", ext)(in_ap=ins["in_ap"], in_t=ins["in_t"], out_qsat=qsat, origin=(0, 0, 0),
+                                        domain=(nx, 1, nz), validate_args=True, exec_info=None)
+    ins["in_qsat"] = qsat
+    outs = {"out_" + n: storage.zeros(nx, nz, np.float64, gpu) for n in NL_OUT}
+    nl = compile_stencil("cloudsc2_nl", ext)
+    nl(**ins, **outs, in_eta=eta, dt=3600.0, origin=(0, 0, 0), domain=(nx, 1, nz + 1), validate_args=True,
+       exec_info=None)
+    c0, n = 70000 - 70000 % 64, 512
+    sub_in = {k: storage.logical_view(storage.klayout(v)[:, c0:c0 + n].contiguous()) for k, v in ins.items()}
+    sub_out = {"out_" + m: storage.zeros(n, nz, np.float64, gpu) for m in NL_OUT}
+    nl(**sub_in, **sub_out, in_eta=eta, dt=3600.0, origin=(0, 0, 0), domain=(n, 1, nz + 1), validate_args=True,
+       exec_info=None)
+    torch.cuda.synchronize()
+    host = {k: storage.klayout(v).cpu().numpy() for k, v in sub_in.items()}
+    want = run_oracle_nl(host, eta.cpu().numpy(), 3600.0, ext)
+    for m in NL_OUT:
+        nlev = 138 if m.startswith("f") else 137
+        big = storage.klayout(outs["out_" + m])[:nlev, c0:c0 + n].cpu().numpy()
+        small = storage.klayout(sub_out["out_" + m])[:nlev].cpu().numpy()
+        assert_close(f"depth-2 vs depth-3 ring out_{m}", big, small, np.float64, rtol_mul=1e-2)
+        assert_close(f"depth-2 ring out_{m}", big, want[m][:nlev])

@@ -133,6 +133,45 @@ inline Ext<T> make_ext(const Cloudsc2Params& p) {
     return e;
 }
 
+// ---- saturation (common/_stencils/saturation.py:23-42 + fcttre.py:22-57), one point -------------------------
+// Shared by saturation_kernel / saturation_vec_kernel (cloudsc2_aux.hip) and the fused-saturation NL variant
+// (cloudsc2_nl.hip).  Contraction is switched off inside: every caller then evaluates the literal sequence of
+// multiplies and adds below (frcp / fexp spell their fma's out), so the three kernels agree bit for bit whatever
+// their surrounding code looks like.  MODE 0: LPHYLIN; 1: not LPHYLIN, KFLAG == 1 (f_foeewmcu); 2: f_foeewm.
+template <typename T>
+__device__ __forceinline__ T foealfa(const Ext<T>& e, T t) {
+#pragma clang fp contract(off)
+    return rmin<T>(T(1.0), sq((rmax<T>(e.RTICE, rmin<T>(e.RTWAT, t)) - e.RTICE) * e.RTWAT_RTICE_R));
+}
+template <typename T>
+__device__ __forceinline__ T foealfcu(const Ext<T>& e, T t) {
+#pragma clang fp contract(off)
+    return rmin<T>(T(1.0), sq((rmax<T>(e.RTICECU, rmin<T>(e.RTWAT, t)) - e.RTICECU) * e.RTWAT_RTICECU_R));
+}
+template <typename T, int MODE>
+__device__ __forceinline__ T saturation_point(const Ext<T>& e, const ExpK<T>& xk, T tt, T app) {
+#pragma clang fp contract(off)
+    const T rap = frcp<T>(app);
+    const T dl = tt - e.R4LES, di = tt - e.R4IES, dtt = tt - e.RTT;
+    const T al = e.R3LES * dtt, ai = e.R3IES * dtt;
+    const T foeewl = fexp<T>(xk, al * frcp<T>(dl));
+    const T foeewi = fexp<T>(xk, ai * frcp<T>(di));
+    T qs;
+    if constexpr (MODE == 0) {
+        const T alfa = foealfa(e, tt);
+        const T wl = alfa * (e.R2ES * foeewl);
+        const T wi = (T(1.0) - alfa) * (e.R2ES * foeewi);
+        qs = rmin<T>((wl + wi) * rap, e.QMAX);
+    } else {
+        const T alfa = (MODE == 1) ? foealfcu(e, tt) : foealfa(e, tt);
+        const T wl = alfa * foeewl;
+        const T wi = (T(1.0) - alfa) * foeewi;
+        qs = rmin<T>(e.R2ES * (wl + wi) * rap, e.QMAX);
+    }
+    const T den = T(1.0) - e.RETV * qs;
+    return qs * frcp<T>(den);
+}
+
 // Pin a wave-uniform value in a VGPR.  The fp64 kernels use ~45 named double constants; together with
 // the 26 field pointers that is far more than the 102 SGPRs of a wave, and hipcc then spills SGPRs to
 // VGPR lanes and pays two v_readlane per 64-bit constant per use.  A constant that lives in a VGPR

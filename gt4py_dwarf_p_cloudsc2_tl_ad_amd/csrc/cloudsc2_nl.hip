@@ -88,16 +88,12 @@ __device__ __forceinline__ NLIn<T> nl_perturb(const NLIn<T>& a, const NLIn<T>& b
     return x;
 }
 
-// saturation, LPHYLIN form (common/_stencils/saturation.py:30-35,42 + f_foealfa, fcttre.py:22-27),
-// same arithmetic as cs2::saturation_kernel<T, 0>.
+// saturation, LPHYLIN form (common/_stencils/saturation.py:30-35,42 + f_foealfa, fcttre.py:22-27): the very function
+// the stand-alone saturation kernels evaluate (cs2::saturation_point, contraction pinned), so the fused variant
+// reproduces their bits.
 template <typename T>
 __device__ __forceinline__ T nl_saturation(const Ext<T>& e, const ExpK<T>& xk, T ap, T t) {
-    const T alfa = rmin<T>(T(1.0), sq((rmax<T>(e.RTICE, rmin<T>(e.RTWAT, t)) - e.RTICE) * e.RTWAT_RTICE_R));
-    const T foeewl = fexp<T>(xk, e.R3LES * (t - e.RTT) * frcp<T>(t - e.R4LES));
-    const T foeewi = fexp<T>(xk, e.R3IES * (t - e.RTT) * frcp<T>(t - e.R4IES));
-    const T foeew = alfa * (e.R2ES * foeewl) + (T(1.0) - alfa) * (e.R2ES * foeewi);
-    const T qs = rmin<T>(foeew * frcp<T>(ap), e.QMAX);
-    return qs * frcp<T>(T(1.0) - e.RETV * qs);
+    return saturation_point<T, 0>(e, xk, t, ap);
 }
 
 template <typename T>

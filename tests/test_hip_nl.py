@@ -73,7 +73,9 @@ def test_nl_short_columns(gpu):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-def test_saturation_matches_oracle(gpu, dtype):
+@pytest.mark.parametrize("nx", [300, 301])
+def test_saturation_matches_oracle(gpu, dtype, nx):
+    """nx = 300: the 16-byte-per-lane kernel (aligned rows); nx = 301: the scalar kernel."""
     import torch
 
     from gt4py_dwarf_p_cloudsc2_tl_ad_amd import storage
@@ -82,12 +84,12 @@ def test_saturation_matches_oracle(gpu, dtype):
 
     for flags in (dict(), dict(LPHYLIN=False, KFLAG=1), dict(LPHYLIN=False, KFLAG=0)):
         ext = externals(**flags)
-        fields, _, _ = nl_case(300, dtype=dtype)
+        fields, _, _ = nl_case(nx, dtype=dtype)
         want = np.zeros_like(fields["in_t"])
         oracle.saturation(fields["in_ap"], fields["in_t"], want, ext)
         dev = to_device({k: fields[k] for k in ("in_ap", "in_t")}, gpu)
-        out = storage.zeros(300, 137, dtype, gpu)
-        compile_stencil("saturation", ext)(**dev, out_qsat=out, origin=(0, 0, 0), domain=(300, 1, 137),
+        out = storage.zeros(nx, 137, dtype, gpu)
+        compile_stencil("saturation", ext)(**dev, out_qsat=out, origin=(0, 0, 0), domain=(nx, 1, 137),
                                             validate_args=True, exec_info=None)
         torch.cuda.synchronize()
         got = from_device(out)

@@ -287,6 +287,43 @@ inline NLK<T> make_nlk(const Cloudsc2Params& p, double dt, bool evap) {
     return k;
 }
 
+// Tropopause pre-scan (nonlinear/_stencils/cloudsc2.py:107-111, same statement in the TL and AD stencils): eta of the
+// LAST level k of the window [klo, khi] (the levels with 0.1 < eta < 0.4) whose first-guess temperature exceeds that
+// of level k+1.  The column's first-guess t of up to 43 levels is needed before the sweep reaches level klo, and
+// with one wave per SIMD a load-compare-load loop exposes the full HBM latency once per level (22 us of a 337 us
+// kernel, measured).  The loads of CH levels are therefore issued back to back and compared afterwards: 3 round
+// trips instead of 42.  (klo, khi) come from build_level_table; khi <= nz - 2, so level khi + 1 exists.
+template <typename T>
+__device__ __forceinline__ T trpaus_prescan(const T* __restrict__ pt, const T* __restrict__ ptt, uint32_t lsb,
+                                            uint32_t colb, T dt, const T* s_eta, int klo, int khi) {
+    T trpaus = T(0.1);
+    if (klo > khi) return trpaus;
+    constexpr int CH = 16;
+    const uint32_t o0 = uint32_t(klo) * lsb + colb;
+    T tk = ldg(pt, o0) + dt * ldg(ptt, o0);
+    for (int k0 = klo; k0 <= khi; k0 += CH) {
+        T a[CH], b[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int kk = (k0 + j < khi ? k0 + j : khi) + 1;   // the tail re-reads level khi + 1 (cache hits)
+            const uint32_t oj = uint32_t(kk) * lsb + colb;
+            a[j] = ldg(pt, oj);
+            b[j] = ldg(ptt, oj);
+        }
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int k = k0 + j;
+            if (k <= khi) {
+                const T tk1 = a[j] + dt * b[j];
+                const T ek = s_eta[k];
+                if (ek > T(0.1) && ek < T(0.4) && tk > tk1) trpaus = ek;
+                tk = tk1;
+            }
+        }
+    }
+    return trpaus;
+}
+
 // Critical relative humidity profile (nonlinear/_stencils/cloudsc2.py:166-186); rh2/deta1 depend on
 // the column's tropopause eta only and are hoisted out of the level loop by the callers.
 template <typename T>

@@ -347,25 +347,6 @@ __device__ __forceinline__ void nl_store(const MPtrs<T, NL_NUM_OUT>& out, const 
     stg(out.p[NL_OUT_FHPSN], i + lsb, -o.sfln * e.RLSTT);
 }
 
-// Tropopause pre-scan (:107-111): eta of the LAST level k in the window with t[k] > t[k+1].
-template <typename T>
-__device__ __forceinline__ T nl_trpaus(const T* __restrict__ pt, const T* __restrict__ ptt, uint32_t lsb,
-                                       uint32_t colb, T dt, const T* s_eta, int klo, int khi) {
-    T trpaus = T(0.1);
-    if (klo <= khi) {
-        uint32_t o = uint32_t(klo) * lsb + colb;
-        T tk = ldg(pt, o) + dt * ldg(ptt, o);
-        for (int k = klo; k <= khi; ++k) {
-            o += lsb;
-            const T tk1 = ldg(pt, o) + dt * ldg(ptt, o);
-            const T ek = s_eta[k];
-            if (ek > T(0.1) && ek < T(0.4) && tk > tk1) trpaus = ek;
-            tk = tk1;
-        }
-    }
-    return trpaus;
-}
-
 #ifndef CS2_F32_WAVES
 #define CS2_F32_WAVES 1   // minimum waves per SIMD requested for the fp32 instantiations (register cap)
 #endif
@@ -420,7 +401,7 @@ nl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
 #endif
     const uint32_t colb = uint32_t(col) * uint32_t(sizeof(T));
 
-    const T trpaus = nl_trpaus<T>(in.p[NL_IN_T], in.p[NL_IN_TND_CML_T], lsb, colb, dt, s_eta, klo, khi);
+    const T trpaus = trpaus_prescan<T>(in.p[NL_IN_T], in.p[NL_IN_TND_CML_T], lsb, colb, dt, s_eta, klo, khi);
     const CrhCol<T> crh = crh_setup<T>(trpaus);
 
     // :93-100
@@ -549,70 +530,78 @@ template <typename T>
 struct RingGeom {
     static constexpr int NPL = 16 / int(sizeof(T));               // columns per lane per DMA = fields per DMA
     static constexpr int NI = NL_NUM_IN / NPL;                    // DMA instructions per level
-    static constexpr int SLOT = NL_NUM_IN * 64 * int(sizeof(T));  // bytes per wave per level
+    static constexpr int DATA = NL_NUM_IN * 64 * int(sizeof(T));  // the 16 input fields of one level
+    static constexpr int SLOT = DATA + 1024;                      // + the tropopause pre-scan pair (one more DMA)
     static constexpr int NSTORE = NL_NUM_OUT;                     // stores per level (nl_store)
 };
 
-// Wait until at most N vector-memory operations are outstanding, then read this lane's column of the 16 fields from
-// the slot at LDS byte address `a` and the level's table entries at `ta` (eta) / `tb` (scalm).
+// Wait until at most N vector-memory operations are outstanding, then read this lane's column of the slot at LDS
+// byte address `a`: the 16 input fields, then the pre-scan pair (first-guess inputs t / tnd_cml_t of level klo + k + 1,
+// fields 16 and 17 of the slot); plus the table entries eta[k] (`ta`), scalm[k] (`tb`), eta[klo + k] (`tc`).
 template <int N>
-__device__ __forceinline__ void ring_read(uint32_t a, uint32_t ta, uint32_t tb, NLIn<double>& x, double& eta_k,
-                                          double& scalm_k) {
+__device__ __forceinline__ void ring_read(uint32_t a, uint32_t ta, uint32_t tb, uint32_t tc, NLIn<double>& x, double& eta_k,
+                                          double& scalm_k, double& ps_t, double& ps_tt, double& eta_ps) {
     asm volatile(
-        "s_waitcnt vmcnt(%21)\n\t"
-            "ds_read_b64 %0, %18\n\t"
-            "ds_read_b64 %1, %18 offset:512\n\t"
-            "ds_read_b64 %2, %18 offset:1024\n\t"
-            "ds_read_b64 %3, %18 offset:1536\n\t"
-            "ds_read_b64 %4, %18 offset:2048\n\t"
-            "ds_read_b64 %5, %18 offset:2560\n\t"
-            "ds_read_b64 %6, %18 offset:3072\n\t"
-            "ds_read_b64 %7, %18 offset:3584\n\t"
-            "ds_read_b64 %8, %18 offset:4096\n\t"
-            "ds_read_b64 %9, %18 offset:4608\n\t"
-            "ds_read_b64 %10, %18 offset:5120\n\t"
-            "ds_read_b64 %11, %18 offset:5632\n\t"
-            "ds_read_b64 %12, %18 offset:6144\n\t"
-            "ds_read_b64 %13, %18 offset:6656\n\t"
-            "ds_read_b64 %14, %18 offset:7168\n\t"
-            "ds_read_b64 %15, %18 offset:7680\n\t"
-            "ds_read_b64 %16, %19\n\t"
-            "ds_read_b64 %17, %20\n\t"
+        "s_waitcnt vmcnt(%25)\n\t"
+            "ds_read_b64 %0, %21\n\t"
+            "ds_read_b64 %1, %21 offset:512\n\t"
+            "ds_read_b64 %2, %21 offset:1024\n\t"
+            "ds_read_b64 %3, %21 offset:1536\n\t"
+            "ds_read_b64 %4, %21 offset:2048\n\t"
+            "ds_read_b64 %5, %21 offset:2560\n\t"
+            "ds_read_b64 %6, %21 offset:3072\n\t"
+            "ds_read_b64 %7, %21 offset:3584\n\t"
+            "ds_read_b64 %8, %21 offset:4096\n\t"
+            "ds_read_b64 %9, %21 offset:4608\n\t"
+            "ds_read_b64 %10, %21 offset:5120\n\t"
+            "ds_read_b64 %11, %21 offset:5632\n\t"
+            "ds_read_b64 %12, %21 offset:6144\n\t"
+            "ds_read_b64 %13, %21 offset:6656\n\t"
+            "ds_read_b64 %14, %21 offset:7168\n\t"
+            "ds_read_b64 %15, %21 offset:7680\n\t"
+            "ds_read_b64 %18, %21 offset:8192\n\t"
+            "ds_read_b64 %19, %21 offset:8704\n\t"
+            "ds_read_b64 %16, %22\n\t"
+            "ds_read_b64 %17, %23\n\t"
+            "ds_read_b64 %20, %24\n\t"
         "s_waitcnt lgkmcnt(0)"
         : "=&v"(x.ap), "=&v"(x.aph1), "=&v"(x.lu1), "=&v"(x.lude), "=&v"(x.mfd), "=&v"(x.mfu), "=&v"(x.q), "=&v"(x.qi),
           "=&v"(x.ql), "=&v"(x.qsat), "=&v"(x.supsat), "=&v"(x.t), "=&v"(x.tq), "=&v"(x.tqi), "=&v"(x.tql), "=&v"(x.tt),
-          "=&v"(eta_k), "=&v"(scalm_k)
-        : "v"(a), "v"(ta), "v"(tb), "n"(N)
+          "=&v"(eta_k), "=&v"(scalm_k), "=&v"(ps_t), "=&v"(ps_tt), "=&v"(eta_ps)
+        : "v"(a), "v"(ta), "v"(tb), "v"(tc), "n"(N)
         : "memory");
 }
 template <int N>
-__device__ __forceinline__ void ring_read(uint32_t a, uint32_t ta, uint32_t tb, NLIn<float>& x, float& eta_k,
-                                          float& scalm_k) {
+__device__ __forceinline__ void ring_read(uint32_t a, uint32_t ta, uint32_t tb, uint32_t tc, NLIn<float>& x, float& eta_k,
+                                          float& scalm_k, float& ps_t, float& ps_tt, float& eta_ps) {
     asm volatile(
-        "s_waitcnt vmcnt(%21)\n\t"
-            "ds_read_b32 %0, %18\n\t"
-            "ds_read_b32 %1, %18 offset:256\n\t"
-            "ds_read_b32 %2, %18 offset:512\n\t"
-            "ds_read_b32 %3, %18 offset:768\n\t"
-            "ds_read_b32 %4, %18 offset:1024\n\t"
-            "ds_read_b32 %5, %18 offset:1280\n\t"
-            "ds_read_b32 %6, %18 offset:1536\n\t"
-            "ds_read_b32 %7, %18 offset:1792\n\t"
-            "ds_read_b32 %8, %18 offset:2048\n\t"
-            "ds_read_b32 %9, %18 offset:2304\n\t"
-            "ds_read_b32 %10, %18 offset:2560\n\t"
-            "ds_read_b32 %11, %18 offset:2816\n\t"
-            "ds_read_b32 %12, %18 offset:3072\n\t"
-            "ds_read_b32 %13, %18 offset:3328\n\t"
-            "ds_read_b32 %14, %18 offset:3584\n\t"
-            "ds_read_b32 %15, %18 offset:3840\n\t"
-            "ds_read_b32 %16, %19\n\t"
-            "ds_read_b32 %17, %20\n\t"
+        "s_waitcnt vmcnt(%25)\n\t"
+            "ds_read_b32 %0, %21\n\t"
+            "ds_read_b32 %1, %21 offset:256\n\t"
+            "ds_read_b32 %2, %21 offset:512\n\t"
+            "ds_read_b32 %3, %21 offset:768\n\t"
+            "ds_read_b32 %4, %21 offset:1024\n\t"
+            "ds_read_b32 %5, %21 offset:1280\n\t"
+            "ds_read_b32 %6, %21 offset:1536\n\t"
+            "ds_read_b32 %7, %21 offset:1792\n\t"
+            "ds_read_b32 %8, %21 offset:2048\n\t"
+            "ds_read_b32 %9, %21 offset:2304\n\t"
+            "ds_read_b32 %10, %21 offset:2560\n\t"
+            "ds_read_b32 %11, %21 offset:2816\n\t"
+            "ds_read_b32 %12, %21 offset:3072\n\t"
+            "ds_read_b32 %13, %21 offset:3328\n\t"
+            "ds_read_b32 %14, %21 offset:3584\n\t"
+            "ds_read_b32 %15, %21 offset:3840\n\t"
+            "ds_read_b32 %18, %21 offset:4096\n\t"
+            "ds_read_b32 %19, %21 offset:4352\n\t"
+            "ds_read_b32 %16, %22\n\t"
+            "ds_read_b32 %17, %23\n\t"
+            "ds_read_b32 %20, %24\n\t"
         "s_waitcnt lgkmcnt(0)"
         : "=&v"(x.ap), "=&v"(x.aph1), "=&v"(x.lu1), "=&v"(x.lude), "=&v"(x.mfd), "=&v"(x.mfu), "=&v"(x.q), "=&v"(x.qi),
           "=&v"(x.ql), "=&v"(x.qsat), "=&v"(x.supsat), "=&v"(x.t), "=&v"(x.tq), "=&v"(x.tqi), "=&v"(x.tql), "=&v"(x.tt),
-          "=&v"(eta_k), "=&v"(scalm_k)
-        : "v"(a), "v"(ta), "v"(tb), "n"(N)
+          "=&v"(eta_k), "=&v"(scalm_k), "=&v"(ps_t), "=&v"(ps_tt), "=&v"(eta_ps)
+        : "v"(a), "v"(ta), "v"(tb), "v"(tc), "n"(N)
         : "memory");
 }
 
@@ -648,8 +637,23 @@ nl_ring_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtr
     const uint32_t lsb = uint32_t(ls) * uint32_t(sizeof(T));
     const uint32_t colb = uint32_t(wcol0 + lane) * uint32_t(sizeof(T));
 
-    const T trpaus = nl_trpaus<T>(in.p[NL_IN_T], in.p[NL_IN_TND_CML_T], lsb, colb, dt, s_eta, klo, khi);
-    const CrhCol<T> crh = crh_setup<T>(trpaus);
+    // Tropopause pre-scan (:107-111), overlapped with the sweep.  crh2 (:166-186) is 1 on every level with
+    // eta <= 0.1 whatever trpaus (>= 0.1) turns out to be, i.e. on all levels above the window [klo, khi] of a
+    // top-down eta grid; the window's first-guess temperatures are therefore fetched by ONE extra DMA per level while
+    // levels 0 .. nps-1 are computed, and trpaus is final before the sweep reaches level klo.  Needs nps <= klo and
+    // eta <= 0.1 above the window (uniform tests); otherwise the pre-scan runs here, before the sweep.
+    const int nps = khi >= klo ? khi - klo + 1 : 0;
+    bool overlap = nps > 0 && nps <= klo;
+    for (int k = 0; k < klo && overlap; ++k) overlap = s_eta[k] <= T(0.1);
+    T trpaus = T(0.1);
+    T tk_ps = T(0.0);
+    if (overlap) {
+        const uint32_t o0 = uint32_t(klo) * lsb + colb;
+        tk_ps = ldg(in.p[NL_IN_T], o0) + dt * ldg(in.p[NL_IN_TND_CML_T], o0);
+    } else {
+        trpaus = trpaus_prescan<T>(in.p[NL_IN_T], in.p[NL_IN_TND_CML_T], lsb, colb, dt, s_eta, klo, khi);
+    }
+    CrhCol<T> crh = crh_setup<T>(overlap ? T(2.0) : trpaus);   // trpaus = 2 > every eta: crh2_at returns 1
 
     // :93-100
     NLCarry<T> c;
@@ -665,6 +669,7 @@ nl_ring_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtr
     // consume the prologue's ordinary loads BEFORE the first DMA is issued: hipcc drains vmcnt(0) at the first use of
     // an ordinary load's result while an LDS-DMA is in flight, which would empty the ring inside level 0
     pin_vgpr(c.aph_k);
+    pin_vgpr(tk_ps);
     if constexpr (EVAP) { T a = aph_s; pin_vgpr(a); }
 
     // per-lane DMA sources: lane group g of instruction i walks field i*NPL + g, NPL adjacent columns per lane;
@@ -685,10 +690,14 @@ nl_ring_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtr
         const uint32_t lev1 = (f == NL_IN_APH || f == NL_IN_LU) ? lsb : 0u;
         src[i] = reinterpret_cast<const char*>(base) + (uint32_t(wcol0 + G::NPL * l) * uint32_t(sizeof(T)) + lev1);
     }
+    // the pre-scan pair: lane groups alternate between t and tnd_cml_t of level klo + 1 + (level being fetched)
+    const char* src_ps = reinterpret_cast<const char*>((g & 1) ? in.p[NL_IN_TND_CML_T] : in.p[NL_IN_T]) +
+                         (uint32_t(wcol0 + G::NPL * l) * uint32_t(sizeof(T)) + uint32_t(klo + 1) * lsb);
+    const int nps_dma = overlap ? nps : 0;
     // LDS: [eta | scalm table][pad][wave 0: RD slots][wave 1: RD slots] ...
     const uint32_t tab_bytes = (2u * uint32_t(nz + 1) * uint32_t(sizeof(T)) + 1023u) & ~1023u;
     const uint32_t ring0 = tab_bytes + uint32_t(wave) * uint32_t(RD * G::SLOT);
-    auto issue = [&](int slot) {
+    auto issue = [&](int slot, int level) {
 #pragma unroll
         for (int i = 0; i < G::NI; ++i) {
             __builtin_amdgcn_global_load_lds((glb_void_ptr)src[i],
@@ -696,10 +705,16 @@ nl_ring_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtr
                                              16, 0, CS2_NT & 1 ? 2 : 0);
             src[i] += lsb;
         }
+        if (level < nps_dma) {   // uniform
+            __builtin_amdgcn_global_load_lds((glb_void_ptr)src_ps,
+                                             (lds_void_ptr)(&smem_raw[ring0 + uint32_t(slot * G::SLOT + G::DATA)]), 16, 0,
+                                             0);   // default cache policy: the sweep reads these rows again
+            src_ps += lsb;
+        }
     };
 #pragma unroll
     for (int j = 0; j < RD - 1; ++j)
-        if (j < nz) issue(j);
+        if (j < nz) issue(j, j);
 
     // Operations younger than level k's DMAs when level k is read (k >= RD-1): (RD-1) x (NI DMAs + NSTORE stores).
     // The wait must never ALLOW more than were really issued, so it is set one level of stores short of that: the
@@ -713,14 +728,22 @@ nl_ring_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtr
     int slot = 0, pslot = RD - 1;
     for (int k = 0; k < nz; ++k) {
         const bool more = k + RD - 1 < nz;
-        if (more) issue(pslot);
+        if (more) issue(pslot, k + RD - 1);
         NLIn<T> x;
-        T eta_k, scalm_k;
+        T eta_k, scalm_k, ps_t, ps_tt, eta_ps;
         const uint32_t a = rd_lane + uint32_t(slot * G::SLOT);
         const uint32_t ta = uint32_t(k) * uint32_t(sizeof(T));
-        if (!more) ring_read<0>(a, ta, ta + tb_off, x, eta_k, scalm_k);            // tail: nothing left in flight
-        else if (k < RD - 1) ring_read<NHEAD>(a, ta, ta + tb_off, x, eta_k, scalm_k);
-        else ring_read<NFULL>(a, ta, ta + tb_off, x, eta_k, scalm_k);
+        const uint32_t tc = uint32_t(klo + k < nz ? klo + k : nz) * uint32_t(sizeof(T));
+        if (!more) ring_read<0>(a, ta, ta + tb_off, tc, x, eta_k, scalm_k, ps_t, ps_tt, eta_ps);   // tail: drain
+        else if (k < RD - 1) ring_read<NHEAD>(a, ta, ta + tb_off, tc, x, eta_k, scalm_k, ps_t, ps_tt, eta_ps);
+        else ring_read<NFULL>(a, ta, ta + tb_off, tc, x, eta_k, scalm_k, ps_t, ps_tt, eta_ps);
+        if (k < nps_dma) {            // pre-scan of level klo + k (:107-111); the slot holds level klo + k + 1
+            const T tk1 = ps_t + dt * ps_tt;
+            if (eta_ps > T(0.1) && eta_ps < T(0.4) && tk_ps > tk1) trpaus = eta_ps;
+            tk_ps = tk1;
+        } else if (k == nps_dma && overlap) {
+            crh = crh_setup<T>(trpaus);   // final before the sweep reaches level klo (nps <= klo)
+        }
         const NLOut<T> r = nl_level<T, EVAP, LIN>(e, kc, xk, x, eta_k, scalm_k, crh, dt, aph_s, c);
         nl_store<T>(out, e, lsb, o, r);
         o += lsb;

@@ -525,24 +525,6 @@ __device__ __forceinline__ void tl_store(const MPtrs<T, NL_NUM_OUT>& out, const 
     stg(out_i.p[NL_OUT_FHPSN], i + lsb, -o.sfln_i * e.RLSTT);
 }
 
-template <typename T>
-__device__ __forceinline__ T tl_trpaus(const T* __restrict__ pt, const T* __restrict__ ptt, uint32_t lsb,
-                                       uint32_t colb, T dt, const T* s_eta, int klo, int khi) {
-    T trpaus = T(0.1);
-    if (klo <= khi) {
-        uint32_t o = uint32_t(klo) * lsb + colb;
-        T tk = ldg(pt, o) + dt * ldg(ptt, o);
-        for (int k = klo; k <= khi; ++k) {
-            o += lsb;
-            const T tk1 = ldg(pt, o) + dt * ldg(ptt, o);
-            const T ek = s_eta[k];
-            if (ek > T(0.1) && ek < T(0.4) && tk > tk1) trpaus = ek;
-            tk = tk1;
-        }
-    }
-    return trpaus;
-}
-
 template <typename T, bool REG, bool EVAP>
 __global__ void __launch_bounds__(kColBlock)
 tl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, NL_NUM_IN> in,
@@ -570,7 +552,7 @@ tl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
     const uint32_t lsb = uint32_t(ls) * uint32_t(sizeof(T));
     const uint32_t colb = uint32_t(col) * uint32_t(sizeof(T));
 
-    const T trpaus = tl_trpaus<T>(in.p[NL_IN_T], in.p[NL_IN_TND_CML_T], lsb, colb, dt, s_eta, klo, khi);
+    const T trpaus = trpaus_prescan<T>(in.p[NL_IN_T], in.p[NL_IN_TND_CML_T], lsb, colb, dt, s_eta, klo, khi);
     const CrhCol<T> crh = crh_setup<T>(trpaus);
 
     // :124-135

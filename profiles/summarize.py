@@ -46,3 +46,10 @@ for k, v in pm.items():
         wc, va, wa = (v[c]["mean_per_dispatch"] for c in ("SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY"))
         line += f", VALU/wave {v['SQ_INSTS_VALU']['mean_per_dispatch'] / v['SQ_WAVES']['mean_per_dispatch']:.0f}, VALU-active {va / wc:.0%}, waiting {wa / wc:.0%}"
     print(line)
+
+# the bench line printed by the profiled run itself (pass 1), for the stats-vs-events comparison
+for line in open(f"gpurun_out/prof_{tag}/trace.log", errors="replace"):
+    if line.startswith('{"metric"'):
+        d = json.loads(line)
+        json.dump(d, open(f"{out}/bench_under_rocprof.json", "w"))
+        print("profiled run's own events: avg_launch_ms", d["roofline"]["avg_launch_ms"], "ms_per_step", d["ms_per_step"])

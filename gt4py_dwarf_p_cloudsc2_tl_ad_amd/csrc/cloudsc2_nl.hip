@@ -605,10 +605,12 @@ __device__ __forceinline__ void ring_read(uint32_t a, uint32_t ta, uint32_t tb, 
         : "memory");
 }
 
-template <typename T, bool EVAP, bool LIN, bool PINK, int RD>
+// SATF: the fused-saturation variant (FUSE = 1 of nl_kernel): in_qsat is not read - its half of the (ql, qsat) DMA
+// re-reads ql, the same bytes the other half fetches - but computed from (ap, t) and written to qsat_out.
+template <typename T, bool EVAP, bool LIN, bool PINK, int RD, bool SATF>
 __global__ void __launch_bounds__(kColBlock, 1)
 nl_ring_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, NL_NUM_IN> in,
-               const T* __restrict__ eta, MPtrs<T, NL_NUM_OUT> out, T dt) {
+               const T* __restrict__ eta, MPtrs<T, NL_NUM_OUT> out, T dt, T* __restrict__ qsat_out) {
     using G = RingGeom<T>;
     static_assert(kColBlock % 64 == 0 && RD >= 2, "whole waves, at least one level in flight");
     static_assert((RD - 1) * (G::NI + G::NSTORE) < 64, "vmcnt is a 6-bit counter");
@@ -687,6 +689,7 @@ nl_ring_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtr
                 base = in.p[i * G::NPL + j];
                 f = i * G::NPL + j;
             }
+        if (SATF && f == NL_IN_QSAT) base = in.p[NL_IN_QL];
         const uint32_t lev1 = (f == NL_IN_APH || f == NL_IN_LU) ? lsb : 0u;
         src[i] = reinterpret_cast<const char*>(base) + (uint32_t(wcol0 + G::NPL * l) * uint32_t(sizeof(T)) + lev1);
     }
@@ -744,6 +747,10 @@ nl_ring_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtr
         } else if (k == nps_dma && overlap) {
             crh = crh_setup<T>(trpaus);   // final before the sweep reaches level klo (nps <= klo)
         }
+        if constexpr (SATF) {
+            x.qsat = nl_saturation<T>(e, xk, x.ap, x.t);
+            stg(qsat_out, o, x.qsat);   // an 11th store per level: not counted in NFULL (under-counting is safe)
+        }
         const NLOut<T> r = nl_level<T, EVAP, LIN>(e, kc, xk, x, eta_k, scalm_k, crh, dt, aph_s, c);
         nl_store<T>(out, e, lsb, o, r);
         o += lsb;
@@ -791,8 +798,9 @@ int launch_nl(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
     // wins (32 768 columns: 244 us vs 259 us at depth 2 vs 299 us register prefetch; 98 304: 609 / 633 / 651 us); with
     // more, LDS occupancy matters more than depth - depth 2 keeps two workgroups resident per CU (131 072 columns:
     // 655 us vs 692 us at depth 3; 262 144: 1 286 vs 1 350 us).
-    bool ring = fuse == 0 && nx % 64 == 0 && nz >= CS2_NL_RING && (ls * int64_t(sizeof(T))) % 16 == 0;
-    for (int i = 0; i < NL_NUM_IN && ring; ++i) ring = reinterpret_cast<uintptr_t>(in[i]) % 16 == 0;
+    bool ring = fuse <= 1 && nx % 64 == 0 && nz >= CS2_NL_RING && (ls * int64_t(sizeof(T))) % 16 == 0;
+    for (int i = 0; i < NL_NUM_IN && ring; ++i)
+        ring = (fuse == 1 && i == NL_IN_QSAT) || reinterpret_cast<uintptr_t>(in[i]) % 16 == 0;
     if (ring) {
         using G = RingGeom<T>;
         int dev = 0;
@@ -807,9 +815,9 @@ int launch_nl(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
         const int depth = deep ? CS2_NL_RING : 2;
         const size_t tab = (2 * size_t(nz + 1) * sizeof(T) + 1023) & ~size_t(1023);
         const size_t rsmem = tab + size_t(kColBlock / 64) * depth * G::SLOT;
-#define CS2_NL_RING_LAUNCH(EV, LN, RD)                                                                               \
+#define CS2_NL_RING_LAUNCH(EV, LN, RD, SF)                                                                           \
     do {                                                                                                             \
-        auto kern = nl_ring_kernel<T, EV, LN, sizeof(T) == 8, RD>;                                                   \
+        auto kern = nl_ring_kernel<T, EV, LN, sizeof(T) == 8, RD, SF>;                                               \
         /* > 64 KB of dynamic LDS needs the opt-in: once per instantiation, device and size */                       \
         static size_t attr_set[64] = {};                                                                             \
         if (attr_set[dev & 63] < rsmem) {                                                                            \
@@ -818,17 +826,23 @@ int launch_nl(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
                 return -1;                                                                                           \
             attr_set[dev & 63] = rsmem;                                                                              \
         }                                                                                                            \
-        hipLaunchKernelGGL(kern, grid, block, rsmem, stream, e, kc, xk, nx, nz, ls, ci, eta, co, tdt);               \
+        hipLaunchKernelGGL(kern, grid, block, rsmem, stream, e, kc, xk, nx, nz, ls, ci, eta, co, tdt, qsat_out);     \
     } while (0)
-#define CS2_NL_RING_FLAGS(RD)                                          \
-    do {                                                               \
-        if (evap && lin) CS2_NL_RING_LAUNCH(true, true, RD);           \
-        else if (evap && !lin) CS2_NL_RING_LAUNCH(true, false, RD);    \
-        else if (!evap && lin) CS2_NL_RING_LAUNCH(false, true, RD);    \
-        else CS2_NL_RING_LAUNCH(false, false, RD);                     \
+#define CS2_NL_RING_FLAGS(RD, SF)                                          \
+    do {                                                                   \
+        if (evap && lin) CS2_NL_RING_LAUNCH(true, true, RD, SF);           \
+        else if (evap && !lin) CS2_NL_RING_LAUNCH(true, false, RD, SF);    \
+        else if (!evap && lin) CS2_NL_RING_LAUNCH(false, true, RD, SF);    \
+        else CS2_NL_RING_LAUNCH(false, false, RD, SF);                     \
     } while (0)
-        if (deep) CS2_NL_RING_FLAGS(CS2_NL_RING);
-        else CS2_NL_RING_FLAGS(2);
+        if (fuse == 1 && !p.LPHYLIN) return -2;   // only the LPHYLIN form of `saturation` is fused
+        if (fuse == 0) {
+            if (deep) CS2_NL_RING_FLAGS(CS2_NL_RING, false);
+            else CS2_NL_RING_FLAGS(2, false);
+        } else {
+            if (deep) CS2_NL_RING_FLAGS(CS2_NL_RING, true);
+            else CS2_NL_RING_FLAGS(2, true);
+        }
 #undef CS2_NL_RING_FLAGS
 #undef CS2_NL_RING_LAUNCH
         return hipGetLastError() == hipSuccess ? 0 : -1;

@@ -323,3 +323,45 @@ def test_large_grid_takes_the_shallow_ring(gpu):
         small = storage.klayout(sub_out["out_" + m])[:nlev].cpu().numpy()
         assert_close(f"depth-2 vs depth-3 ring out_{m}", big, small, np.float64, rtol_mul=1e-2)
         assert_close(f"depth-2 ring out_{m}", big, want[m][:nlev])
+
+
+def test_ring_kernel_is_deterministic_under_load(gpu):
+    """The LDS-ring kernels wait on hand-counted vmcnt values; a wrong count would show as run-to-run differences
+    (a lane reading a slot before its DMA landed).  200 launches at the headline size, alternating with the
+    fused-saturation ring kernel and a large copy that perturbs memory latency, must all give the first launch's bits."""
+    import torch
+
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd import storage
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.stencils import compile_stencil
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.synthetic import eta_levels, make_state
+
+    nx, nz = 65536, 137
+    ext = externals()
+    s = make_state(nx, nz, device=gpu)
+    eta = torch.as_tensor(eta_levels(nz), device=gpu)
+    ins = {"in_" + k[2:]: storage.logical_view(v) for k, v in s.items()}
+    qsat = storage.zeros(nx, nz, np.float64, gpu)
+    com = dict(origin=(0, 0, 0), validate_args=False, exec_info=None)
+    compile_stencil("saturation", ext)(in_ap=ins["in_ap"], in_t=ins["in_t"], out_qsat=qsat, domain=(nx, 1, nz), **com)
+    nl = compile_stencil("cloudsc2_nl", ext)
+    nls = compile_stencil("cloudsc2_nl_saturation", ext)
+    ins_q = dict(ins, in_qsat=qsat)
+    ref = {"out_" + n: storage.zeros(nx, nz, np.float64, gpu) for n in NL_OUT}
+    nl(**ins_q, **ref, in_eta=eta, dt=3600.0, domain=(nx, 1, nz + 1), **com)
+    out = {"out_" + n: storage.zeros(nx, nz, np.float64, gpu) for n in NL_OUT}
+    q2 = storage.zeros(nx, nz, np.float64, gpu)
+    big_a = torch.empty(1 << 26, dtype=torch.float64, device=gpu)
+    big_b = torch.empty_like(big_a)
+    bad = torch.zeros((), dtype=torch.int64, device=gpu)
+    for it in range(200):
+        if it % 3 == 2:
+            big_b.copy_(big_a, non_blocking=True)
+        if it % 2:
+            nls(**ins, out_qsat=q2, **out, in_eta=eta, dt=3600.0, domain=(nx, 1, nz + 1), **com)
+            bad += (q2 != qsat).sum()
+        else:
+            nl(**ins_q, **out, in_eta=eta, dt=3600.0, domain=(nx, 1, nz + 1), **com)
+        for n in ("out_tnd_t", "out_fplsn", "out_clc"):
+            bad += (out[n] != ref[n]).sum()
+    torch.cuda.synchronize()
+    assert int(bad) == 0

@@ -523,6 +523,9 @@ nl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
 #ifndef CS2_NL_RING
 #define CS2_NL_RING 3   // slots per wave (levels in flight + the one being computed); 0 disables the variant
 #endif
+#ifndef CS2_NL_RING_AUX
+#define CS2_NL_RING_AUX (CS2_NT & 1 ? 2 : 0)   // cache policy of the input DMAs: 2 = nt (every byte is read once)
+#endif
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef const __attribute__((address_space(1))) void* glb_void_ptr;
 
@@ -705,7 +708,7 @@ nl_ring_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtr
         for (int i = 0; i < G::NI; ++i) {
             __builtin_amdgcn_global_load_lds((glb_void_ptr)src[i],
                                              (lds_void_ptr)(&smem_raw[ring0 + uint32_t(slot * G::SLOT + i * 1024)]),
-                                             16, 0, CS2_NT & 1 ? 2 : 0);
+                                             16, 0, CS2_NL_RING_AUX);
             src[i] += lsb;
         }
         if (level < nps_dma) {   // uniform

@@ -3,14 +3,14 @@
 from __future__ import annotations
 
 import contextlib
-from typing import Any, Dict, Iterator, Sequence, Tuple
+from typing import Any, Iterator, Sequence, Tuple
 
 import numpy as np
 import torch
 
 from .. import storage
 from .backends import backend_device
-from .grid import K, DimSymbol
+from .grid import DimSymbol
 
 
 class FieldTensor(torch.Tensor):

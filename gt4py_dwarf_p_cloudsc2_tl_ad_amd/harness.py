@@ -22,7 +22,6 @@ from typing import Any, Dict, List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-from . import storage
 from .framework.timing import timing
 from .physics import (Cloudsc2AD, Cloudsc2NL, Cloudsc2NLPerturbed, Cloudsc2TL, PerturbedState, Saturation,
                       StateIncrement)

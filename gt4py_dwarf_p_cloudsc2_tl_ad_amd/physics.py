@@ -19,9 +19,7 @@ from __future__ import annotations
 
 from datetime import timedelta
 from functools import cached_property
-from typing import Any, Dict, Mapping
-
-import torch
+from typing import Any, Dict
 
 from .framework.components import DiagnosticComponent, ImplicitTendencyComponent
 from .framework.grid import I, J, K

@@ -15,7 +15,7 @@ Error behaviour mirrors GT4Py's: argument problems found with ``validate_args=Tr
 from __future__ import annotations
 
 import ctypes
-from typing import Any, Callable, Dict, Mapping, Optional, Sequence, Tuple
+from typing import Any, Callable, Dict, Mapping, Optional, Sequence
 
 import torch
 

@@ -6,8 +6,7 @@ compare tendencies and diagnostics field by field) with the oracle in the role o
 import numpy as np
 import pytest
 
-from helpers import (NL_IN, NL_OUT, assert_close, externals, from_device, nl_case, run_oracle_nl,
-                     to_device)
+from helpers import (NL_OUT, assert_close, externals, from_device, nl_case, run_oracle_nl, to_device)
 
 pytestmark = pytest.mark.gpu
 

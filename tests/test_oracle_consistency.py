@@ -2,10 +2,8 @@
 reference's own test strategy: Taylor test (TL vs finite differences of NL,
 tangent_linear/validation.py:150-261) and symmetry test (AD vs TL, adjoint/validation.py:132-215)."""
 import numpy as np
-import pytest
 
-from helpers import (NL_IN, NL_OUT, externals, increments, nl_case, nlev_of, run_oracle_ad, run_oracle_nl,
-                     run_oracle_tl, symmetry_norm3, taylor_norms, taylor_verdict)
+from helpers import (NL_OUT, externals, increments, nl_case, nlev_of, run_oracle_ad, run_oracle_nl, run_oracle_tl, symmetry_norm3, taylor_norms)
 from oracle import cloudsc2_numpy as oracle
 
 F2S = tuple(10.0 ** -i for i in range(1, 11))

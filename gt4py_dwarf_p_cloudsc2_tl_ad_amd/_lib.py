@@ -14,7 +14,8 @@ from typing import Optional
 from .params import ABI_VERSION, Cloudsc2Params
 
 LIB_NAME = "libcloudsc2_hip.so"
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+#: CLOUDSC2_HIP_LIB overrides the library file (dev / A-B builds made by profiles/build_variants.sh); same checks apply
+LIB_PATH = os.environ.get("CLOUDSC2_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 NL_NUM_IN = 16
 NL_NUM_OUT = 10

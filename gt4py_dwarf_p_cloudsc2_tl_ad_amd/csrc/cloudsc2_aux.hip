@@ -10,6 +10,11 @@
 namespace cs2 {
 
 constexpr int kAuxBlock = 256;
+// qsat stores: 0 = default cache policy - the consumer (cloudsc2_nl) follows immediately (run_nonlinear.py:117-118) and finds
+// the 72 MB field in the 256 MB memory-side cache (saturation + NL: 391 -> 370 us); 1 = non-temporal like every other store
+#ifndef CS2_SAT_NT_STORE
+#define CS2_SAT_NT_STORE 0
+#endif
 
 // MODE 0: LPHYLIN; MODE 1: not LPHYLIN, KFLAG == 1 (f_foeewmcu); MODE 2: not LPHYLIN, KFLAG != 1 (f_foeewm)
 template <typename T, int MODE>
@@ -19,7 +24,11 @@ saturation_kernel(Ext<T> e, ExpK<T> xk, int nx, int64_t ls, const T* __restrict_
     const int col = blockIdx.x * kAuxBlock + threadIdx.x;
     if (col >= nx) return;
     const int64_t i = int64_t(blockIdx.y) * ls + col;
+#if CS2_SAT_NT_STORE
     ntstore(qsat + i, saturation_point<T, MODE>(e, xk, ntload(t + i), ntload(ap + i)));
+#else
+    qsat[i] = saturation_point<T, MODE>(e, xk, ntload(t + i), ntload(ap + i));
+#endif
 }
 
 // Vector form for aligned storages: 16 bytes per lane (2 fp64 / 4 fp32 columns) and LPT levels per thread, all loads
@@ -49,7 +58,11 @@ saturation_vec_kernel(Ext<T> e, ExpK<T> xk, int nxv, int nz, int64_t ls, const T
         vec_t r;
 #pragma unroll
         for (int v = 0; v < V; ++v) r[v] = saturation_point<T, MODE>(e, xk, vt[j][v], va[j][v]);
+#if CS2_SAT_NT_STORE
         __builtin_nontemporal_store(r, reinterpret_cast<vec_t*>(qsat + int64_t(k0 + j) * ls + int64_t(cv) * V));
+#else
+        *reinterpret_cast<vec_t*>(qsat + int64_t(k0 + j) * ls + int64_t(cv) * V) = r;
+#endif
     }
 }
 

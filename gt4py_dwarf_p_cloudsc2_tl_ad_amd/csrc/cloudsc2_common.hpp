@@ -208,6 +208,13 @@ __device__ __forceinline__ void stg(T* base, uint32_t boff, T v) {
     *a = v;
 #endif
 }
+// Default-policy load for the ONE field with a producer just upstream: `in_qsat` is written by `saturation` right before
+// cloudsc2_nl reads it (run_nonlinear.py:117-118) and, at 72 MB for 65 536 columns, is still in the 256 MB
+// memory-side cache - unless the store or the load is marked non-temporal (measured: saturation + NL 391 -> 370 us).
+template <typename T>
+__device__ __forceinline__ T ldg_keep(const T* base, uint32_t boff) {
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + boff);
+}
 // streaming access for the pointwise helper kernels (64-bit indexing, same CS2_NT policy)
 template <typename T>
 __device__ __forceinline__ T ntload(const T* a) {

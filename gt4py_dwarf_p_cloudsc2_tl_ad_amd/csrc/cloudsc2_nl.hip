@@ -62,7 +62,7 @@ __device__ __forceinline__ NLIn<T> nl_load_impl(const CPtrs<T, NL_NUM_IN>& in, u
     x.q = ldg(in.p[NL_IN_Q], o);
     x.qi = ldg(in.p[NL_IN_QI], o);
     x.ql = ldg(in.p[NL_IN_QL], o);
-    x.qsat = skipq ? T(0.0) : ldg(in.p[NL_IN_QSAT], o);
+    x.qsat = skipq ? T(0.0) : ldg_keep(in.p[NL_IN_QSAT], o);   // just written by `saturation`: let it hit the cache
     x.supsat = ldg(in.p[NL_IN_SUPSAT], o);
     x.t = ldg(in.p[NL_IN_T], o);
     x.tq = ldg(in.p[NL_IN_TND_CML_Q], o);
@@ -526,6 +526,11 @@ nl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
 #ifndef CS2_NL_RING_AUX
 #define CS2_NL_RING_AUX (CS2_NT & 1 ? 2 : 0)   // cache policy of the input DMAs: 2 = nt (every byte is read once)
 #endif
+// Cache policy of the DMA that carries in_qsat: default (0), not nt - `saturation` wrote the field just before
+// (run_nonlinear.py:117-118) and it is still in the 256 MB memory-side cache.  -1: same policy as the other inputs.
+#ifndef CS2_NL_QSAT_AUX
+#define CS2_NL_QSAT_AUX 0
+#endif
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef const __attribute__((address_space(1))) void* glb_void_ptr;
 
@@ -706,9 +711,15 @@ nl_ring_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtr
     auto issue = [&](int slot, int level) {
 #pragma unroll
         for (int i = 0; i < G::NI; ++i) {
-            __builtin_amdgcn_global_load_lds((glb_void_ptr)src[i],
-                                             (lds_void_ptr)(&smem_raw[ring0 + uint32_t(slot * G::SLOT + i * 1024)]),
-                                             16, 0, CS2_NL_RING_AUX);
+            // (the cache-policy operand must be a literal constant at each call site)
+            if (CS2_NL_QSAT_AUX >= 0 && i == NL_IN_QSAT / G::NPL)
+                __builtin_amdgcn_global_load_lds((glb_void_ptr)src[i],
+                                                 (lds_void_ptr)(&smem_raw[ring0 + uint32_t(slot * G::SLOT + i * 1024)]),
+                                                 16, 0, CS2_NL_QSAT_AUX >= 0 ? CS2_NL_QSAT_AUX : 0);
+            else
+                __builtin_amdgcn_global_load_lds((glb_void_ptr)src[i],
+                                                 (lds_void_ptr)(&smem_raw[ring0 + uint32_t(slot * G::SLOT + i * 1024)]),
+                                                 16, 0, CS2_NL_RING_AUX);
             src[i] += lsb;
         }
         if (level < nps_dma) {   // uniform

@@ -260,14 +260,19 @@ def main():
     # event-timed passes above on purpose: those ~150 launches bring the GPU out of its idle power state, so that the
     # wall-clock figure is not dominated by the clock ramp of the first milliseconds (with 5 warm-up steps straight
     # from idle the same 50 steps measured 377 us per step instead of 343 us, profiles/host_overhead.py).
+    import gc
+
     for _ in range(args.warmup):
         step()
+    gc.collect()
+    gc.disable()        # no collector pause inside the wall-clock window (every stencil call builds small ctypes arrays)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -270,8 +270,9 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0      # this rank's K steps, from the common start to its own completion
+    barrier()                               # closing bracket; the job time is the MAX over ranks taken below
     gc.enable()
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)

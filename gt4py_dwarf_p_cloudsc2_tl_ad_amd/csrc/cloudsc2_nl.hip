@@ -11,6 +11,10 @@
 //   flux shift out_fpls*[k+1] = flux leaving level k, enthalpy fluxes (:391-399) - fused into the
 //              sweep, so the fluxes are written once and never re-read.
 //
+// Two kernels share nl_level / nl_store: nl_kernel (register prefetch; any shape, and the perturbed / Taylor fused
+// variants) and nl_ring_kernel (LDS-DMA ring, two levels in flight, tropopause pre-scan overlapped with the sweep;
+// whole waves and 16-byte aligned rows - the path the headline configuration takes).  launch_nl picks.
+//
 // Template flags: EVAP = LEVAPLS2 or LDRAIN1D (precipitation evaporation block :288-321 and the
 // 1.9*RCLCRIT / 1e-4 thresholds :250-266), LIN = LPHYLIN or LDRAIN1D (:141-155).
 #include "cloudsc2_common.hpp"
@@ -23,7 +27,7 @@
 #define CS2_NL_PINK 1   // pin the named physical constants in VGPRs (fp64 only)
 #endif
 #ifndef CS2_NL_PREFETCH
-#define CS2_NL_PREFETCH 1   // levels in flight ahead of the one being computed (1 measured best: the
+#define CS2_NL_PREFETCH 1   // register path: levels in flight ahead of the one being computed (1 measured best: the
 #endif                      // access pattern, not latency, bounds the kernel - profiles/microbench_stream.hip)
 #ifndef CS2_NL_DIAG
 #define CS2_NL_DIAG 0   // diagnostics only (wrong results): 1 = memory traffic without the physics,

@@ -282,10 +282,11 @@ __device__ __forceinline__ NLOut<T> nl_level(const Ext<T>& e, const NLK<T>& kc, 
             preclr -= dpr;
             if (preclr <= T(0.0)) c.covptot = clc;
             o.covptot = c.covptot;
-            const T rprtot = frcp<T>(prtot);
-            evapr = dpr * rfln * rprtot;
+            // IEEE division: when everything evaporates (dpr == preclr == prtot) the flux must become exactly 0, as in
+            // the reference - an approximate reciprocal leaves a 1e-16-relative residue that later levels carry along
+            evapr = dpr * rfln / prtot;
             rfln -= evapr;
-            evaps = dpr * sfln * rprtot;
+            evaps = dpr * sfln / prtot;
             sfln -= evaps;
         }
     }

@@ -817,6 +817,7 @@ int launch_nl(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
     // wins (32 768 columns: 244 us vs 259 us at depth 2 vs 299 us register prefetch; 98 304: 609 / 633 / 651 us); with
     // more, LDS occupancy matters more than depth - depth 2 keeps two workgroups resident per CU (131 072 columns:
     // 655 us vs 692 us at depth 3; 262 144: 1 286 vs 1 350 us).
+    bool ring_deep = true;
     bool ring = fuse <= 1 && nx % 64 == 0 && nz >= CS2_NL_RING && (ls * int64_t(sizeof(T))) % 16 == 0;
     for (int i = 0; i < NL_NUM_IN && ring; ++i)
         ring = (fuse == 1 && i == NL_IN_QSAT) || reinterpret_cast<uintptr_t>(in[i]) % 16 == 0;
@@ -831,6 +832,17 @@ int launch_nl(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
             cus[dev & 63] = n;
         }
         const bool deep = int64_t(grid.x) * 2 <= int64_t(cus[dev & 63]) * 3;
+        ring_deep = deep;
+        const int depth = deep ? CS2_NL_RING : 2;
+        const size_t tab = (2 * size_t(nz + 1) * sizeof(T) + 1023) & ~size_t(1023);
+        const size_t rsmem = tab + size_t(kColBlock / 64) * depth * G::SLOT;
+        ring = rsmem <= size_t(160) * 1024;   // LDS of a CU; very tall columns (table > 46 KB) take the register path
+    }
+    if (ring) {
+        using G = RingGeom<T>;
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return -1;
+        const bool deep = ring_deep;
         const int depth = deep ? CS2_NL_RING : 2;
         const size_t tab = (2 * size_t(nz + 1) * sizeof(T) + 1023) & ~size_t(1023);
         const size_t rsmem = tab + size_t(kColBlock / 64) * depth * G::SLOT;

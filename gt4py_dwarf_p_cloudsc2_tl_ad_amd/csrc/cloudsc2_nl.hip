@@ -531,6 +531,14 @@ nl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
 #ifndef CS2_NL_RING_AUX
 #define CS2_NL_RING_AUX (CS2_NT & 1 ? 2 : 0)   // cache policy of the input DMAs: 2 = nt (every byte is read once)
 #endif
+// 1: the sweep's own reads of t / tnd_cml_t on the tropopause-window levels use the default cache policy, hoping to hit
+// the rows the overlapped pre-scan fetched.  Measured and left OFF: it gains 9 us only in a back-to-back train of
+// launches, i.e. from what the PREVIOUS launch left in the memory-side cache; with the cache evicted between steps
+// it is 4 us slower (profiles/cold_cache_check.py).  The committed configuration times the same with or without
+// that eviction - only in_qsat, produced inside the step, is meant to be found in cache.
+#ifndef CS2_NL_PS_REUSE
+#define CS2_NL_PS_REUSE 0
+#endif
 // Cache policy of the DMA that carries in_qsat: default (0), not nt - `saturation` wrote the field just before
 // (run_nonlinear.py:117-118) and it is still in the 256 MB memory-side cache.  -1: same policy as the other inputs.
 #ifndef CS2_NL_QSAT_AUX
@@ -714,6 +722,7 @@ nl_ring_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtr
     const uint32_t tab_bytes = (2u * uint32_t(nz + 1) * uint32_t(sizeof(T)) + 1023u) & ~1023u;
     const uint32_t ring0 = tab_bytes + uint32_t(wave) * uint32_t(RD * G::SLOT);
     auto issue = [&](int slot, int level) {
+        const bool in_window = nps_dma > 0 && level > klo && level <= khi + 1;   // uniform
 #pragma unroll
         for (int i = 0; i < G::NI; ++i) {
             // (the cache-policy operand must be a literal constant at each call site)
@@ -721,6 +730,11 @@ nl_ring_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtr
                 __builtin_amdgcn_global_load_lds((glb_void_ptr)src[i],
                                                  (lds_void_ptr)(&smem_raw[ring0 + uint32_t(slot * G::SLOT + i * 1024)]),
                                                  16, 0, CS2_NL_QSAT_AUX >= 0 ? CS2_NL_QSAT_AUX : 0);
+            else if (CS2_NL_PS_REUSE && in_window && (i == NL_IN_T / G::NPL || i == NL_IN_TND_CML_T / G::NPL))
+                // the pre-scan DMA fetched this row of t / tnd_cml_t (default policy) a few tens of levels ago
+                __builtin_amdgcn_global_load_lds((glb_void_ptr)src[i],
+                                                 (lds_void_ptr)(&smem_raw[ring0 + uint32_t(slot * G::SLOT + i * 1024)]),
+                                                 16, 0, 0);
             else
                 __builtin_amdgcn_global_load_lds((glb_void_ptr)src[i],
                                                  (lds_void_ptr)(&smem_raw[ring0 + uint32_t(slot * G::SLOT + i * 1024)]),

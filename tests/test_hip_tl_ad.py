@@ -300,3 +300,31 @@ def test_ad_evaporation_block_matches_oracle(gpu, sw):
         k = 138 if n in ("aph", "lu") else 137
         # out_lu_i inherits the cancellation inside a_clc (tests/test_reference_exec.py)
         _assert_close_by_column(f"ad-evap out_{n}_i", got_i[n][:k], want_i[n][:k], 1e-4 if n == "lu" else 1e-8)
+
+
+@pytest.mark.parametrize("kind", ["tl", "ad"])
+def test_evaporation_block_fp32_instantiations(gpu, kind):
+    """fp32 builds of the TL / AD evaporation block: the trajectory half must match the fp32 oracle within the fp32
+    tolerance of tests/helpers.py and every perturbation / adjoint output must be finite (their values are not compared:
+    in single precision the block's cancellations leave few significant digits even at dt = 60 s)."""
+    nx, dt = 256, 60.0
+    ext = externals(NLEV=137, LEVAPLS2=True, LREGCL=True)
+    fields, eta, _ = nl_case(nx, dtype=np.float32, ext=ext)
+    rng = np.random.default_rng(9)
+    fi = {k: (v * rng.uniform(0.5, 1.5, size=v.shape)).astype(np.float32)
+          for k, v in increments(fields, 0.01, ignore_supsat=True).items()}
+    want, want_i = run_oracle_tl(fields, fi, eta, dt, ext)
+    if kind == "tl":
+        got, got_i = run_hip_tl(fields, fi, eta, dt, ext, gpu, nx, 137)
+        outs_i = {n: got_i[n][:nlev_of(n, 137)] for n in NL_OUT}
+    else:
+        forcing = {n: np.nan_to_num(want_i[n], posinf=0.0, neginf=0.0).astype(np.float32) for n in NL_OUT}
+        want, _ = run_oracle_ad(fields, forcing, eta, dt, ext)   # the AD stencil's own trajectory (quirks Q4 / Q10)
+        got, got_i = run_hip_ad(fields, forcing, eta, dt, ext, gpu, nx, 137)
+        outs_i = {n: got_i[n][:(138 if n in ("aph", "lu") else 137)] for n in NL_IN}
+    assert np.abs(want["covptot"]).max() > 0
+    for n in NL_OUT:
+        k = nlev_of(n, 137)
+        assert_close(f"{kind}-evap fp32 out_{n}", got[n][:k], want[n][:k], np.float32)
+    for n, v in outs_i.items():
+        assert np.isfinite(v).all(), n

@@ -56,6 +56,9 @@ int check_ptrs(const char* fn, const char* what, const T* const* arr, int n) {
 
 int launched(const char* fn, int rc) {
     if (rc == 0) return CLOUDSC2_OK;
+    if (rc == -2)   // the launchers' one refusal: a field larger than 4 GiB (the kernels address it with 32-bit byte offsets)
+        return fail(CLOUDSC2_E_UNSUPPORTED,
+                    "%s: (nz+1) * lev_stride * sizeof(element) must be < 2^32 bytes per field - split the columns into blocks", fn);
     return fail(CLOUDSC2_E_LAUNCH, "%s: HIP launch failed: %s", fn, hipGetErrorString(hipPeekAtLastError()));
 }
 

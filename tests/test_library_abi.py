@@ -78,3 +78,29 @@ def test_stencil_rejects_cpu_tensors(hip_lib):
         st(in_ap=a, in_t=a, out_qsat=a, origin=(0, 0, 0), domain=(8, 1, 5), validate_args=True, exec_info=None)
     with pytest.raises(KeyError):
         compile_stencil("no_such_stencil", {})
+
+
+def test_size_limits_and_empty_calls(hip_lib):
+    """Edge sizes are settled on the host, before any launch: a field beyond 4 GiB (32-bit byte offsets inside a field)
+    is refused with CLOUDSC2_E_UNSUPPORTED and a message that says what to do; nx = 0 is a successful no-op."""
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd import _lib
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.params import default_externals, make_params
+
+    p = make_params(dict(default_externals(), NLEV=137))
+    ins, ins_i = _lib.ptr_array([4096] * 16), _lib.ptr_array([4096] * 16)      # never dereferenced on these paths
+    outs, outs_i = _lib.ptr_array([4096] * 10), _lib.ptr_array([4096] * 10)
+    big = 4_000_000                                                              # x 138 levels x 8 B > 2^32
+    assert hip_lib.cloudsc2_nl_f64(ctypes.byref(p), big, 137, big, ins, 4096, outs, 3600.0, None) == -2
+    assert "2^32" in _lib.last_error()
+    assert hip_lib.cloudsc2_tl_f64(ctypes.byref(p), big, 137, big, ins, ins_i, 4096, outs, outs_i, 3600.0, None) == -2
+    assert hip_lib.cloudsc2_ad_f64(ctypes.byref(p), big, 137, big, ins, outs, 4096, outs, ins_i, 3600.0, None) == -2
+    with pytest.raises(ValueError, match="2\\^32"):
+        _lib.check(-2, "cloudsc2_nl")
+    # fp32 halves the footprint: the same shape is accepted by the size check (and would launch on a GPU)
+    for fn, args in (("cloudsc2_nl_f64", (ins, 4096, outs, 3600.0, None)),
+                     ("cloudsc2_tl_f64", (ins, ins_i, 4096, outs, outs_i, 3600.0, None)),
+                     ("cloudsc2_ad_f64", (ins, outs, 4096, outs, ins_i, 3600.0, None)),
+                     ("cloudsc2_saturation_f64", (4096, 4096, 4096, None)),
+                     ("cloudsc2_state_increment_f64", (ins, ins_i, 0.01, None)),
+                     ("cloudsc2_perturbed_state_f64", (ins, ins_i, ins, 0.001, None))):
+        assert getattr(hip_lib, fn)(ctypes.byref(p), 0, 137, 64, *args) == 0, fn

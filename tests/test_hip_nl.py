@@ -364,3 +364,47 @@ def test_ring_kernel_is_deterministic_under_load(gpu):
             bad += (out[n] != ref[n]).sum()
     torch.cuda.synchronize()
     assert int(bad) == 0
+
+
+def test_config5_shard_fp32(gpu):
+    """BASELINE config 5, one GPU's share: CLOUDSC2-NL fp32 on 524 288 columns x 137 levels (4 194 304 columns over 8 GPUs).
+    Size-independent checks on the whole shard (finite, cover in [0, 1], non-negative fluxes, enthalpy-flux identity),
+    equality with a separate call on a 512-column block, and the oracle on that block."""
+    import torch
+
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd import storage
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.stencils import compile_stencil
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.synthetic import eta_levels, make_state
+
+    total, nx, nz, rank = 4194304, 524288, 137, 3
+    ext = externals()
+    s = make_state(total, nz, col0=rank * nx, ncols=nx, dtype=np.float32, device=gpu)
+    eta = torch.as_tensor(eta_levels(nz, dtype=np.float32), device=gpu)
+    ins = {"in_" + k[2:]: storage.logical_view(v) for k, v in s.items()}
+    qsat = storage.zeros(nx, nz, np.float32, gpu)
+    com = dict(origin=(0, 0, 0), validate_args=True, exec_info=None)
+    compile_stencil("saturation", ext)(in_ap=ins["in_ap"], in_t=ins["in_t"], out_qsat=qsat, domain=(nx, 1, nz), **com)
+    ins["in_qsat"] = qsat
+    outs = {"out_" + n: storage.zeros(nx, nz, np.float32, gpu) for n in NL_OUT}
+    nl = compile_stencil("cloudsc2_nl", ext)
+    nl(**ins, **outs, in_eta=eta, dt=3600.0, domain=(nx, 1, nz + 1), **com)
+    o = {n: storage.klayout(outs["out_" + n]) for n in NL_OUT}
+    for n in NL_OUT:
+        assert bool(torch.isfinite(o[n]).all()), n
+    assert float(o["clc"].min()) >= 0.0 and float(o["clc"].max()) <= 1.0
+    assert float(o["fplsl"].min()) >= -1e-12 and float(o["fplsn"].min()) >= -1e-12
+    assert torch.allclose(o["fhpsl"], -o["fplsl"] * np.float32(ext["RLVTT"]), rtol=1e-6, atol=0.0)
+    assert torch.allclose(o["fhpsn"], -o["fplsn"] * np.float32(ext["RLSTT"]), rtol=1e-6, atol=0.0)
+    c0, n = 300032, 512
+    sub_in = {k: storage.logical_view(storage.klayout(v)[:, c0:c0 + n].contiguous()) for k, v in ins.items()}
+    sub_out = {"out_" + m: storage.zeros(n, nz, np.float32, gpu) for m in NL_OUT}
+    nl(**sub_in, **sub_out, in_eta=eta, dt=3600.0, domain=(n, 1, nz + 1), **com)
+    torch.cuda.synchronize()
+    host = {k: storage.klayout(v).cpu().numpy() for k, v in sub_in.items()}
+    want = run_oracle_nl(host, eta.cpu().numpy(), 3600.0, ext)
+    for m in NL_OUT:
+        nlev = 138 if m.startswith("f") else 137
+        big = o[m][:nlev, c0:c0 + n].cpu().numpy()
+        small = storage.klayout(sub_out["out_" + m])[:nlev].cpu().numpy()
+        assert_close(f"shard vs block out_{m}", big, small, np.float32, rtol_mul=1e-2)
+        assert_close(f"shard out_{m}", big, want[m][:nlev], np.float32)

@@ -10,8 +10,9 @@
 namespace cs2 {
 
 constexpr int kAuxBlock = 256;
-// qsat stores: 0 = default cache policy - the consumer (cloudsc2_nl) follows immediately (run_nonlinear.py:117-118) and finds
-// the 72 MB field in the 256 MB memory-side cache (saturation + NL: 391 -> 370 us); 1 = non-temporal like every other store
+// qsat stores: `keep` != 0 (launcher: the field fits the memory-side cache, qsat_fits_cache) -> default cache policy, the
+// consumer (cloudsc2_nl) follows immediately and finds the field there; otherwise non-temporal like every other store.
+// CS2_SAT_NT_STORE = 1 forces non-temporal stores (A/B switch).
 #ifndef CS2_SAT_NT_STORE
 #define CS2_SAT_NT_STORE 0
 #endif
@@ -20,15 +21,13 @@ constexpr int kAuxBlock = 256;
 template <typename T, int MODE>
 __global__ void __launch_bounds__(kAuxBlock)
 saturation_kernel(Ext<T> e, ExpK<T> xk, int nx, int64_t ls, const T* __restrict__ ap, const T* __restrict__ t,
-                  T* __restrict__ qsat) {
+                  T* __restrict__ qsat, int keep) {
     const int col = blockIdx.x * kAuxBlock + threadIdx.x;
     if (col >= nx) return;
     const int64_t i = int64_t(blockIdx.y) * ls + col;
-#if CS2_SAT_NT_STORE
-    ntstore(qsat + i, saturation_point<T, MODE>(e, xk, ntload(t + i), ntload(ap + i)));
-#else
-    qsat[i] = saturation_point<T, MODE>(e, xk, ntload(t + i), ntload(ap + i));
-#endif
+    const T r = saturation_point<T, MODE>(e, xk, ntload(t + i), ntload(ap + i));
+    if (keep && !CS2_SAT_NT_STORE) qsat[i] = r;
+    else ntstore(qsat + i, r);
 }
 
 // Vector form for aligned storages: 16 bytes per lane (2 fp64 / 4 fp32 columns) and LPT levels per thread, all loads
@@ -38,7 +37,7 @@ constexpr int kSatLPT = 4;
 template <typename T, int MODE>
 __global__ void __launch_bounds__(kAuxBlock)
 saturation_vec_kernel(Ext<T> e, ExpK<T> xk, int nxv, int nz, int64_t ls, const T* __restrict__ ap, const T* __restrict__ t,
-                      T* __restrict__ qsat) {
+                      T* __restrict__ qsat, int keep) {
     constexpr int V = 16 / int(sizeof(T));
     typedef T vec_t __attribute__((ext_vector_type(V)));
     const int cv = blockIdx.x * kAuxBlock + threadIdx.x;   // index of this lane's group of V columns
@@ -58,11 +57,9 @@ saturation_vec_kernel(Ext<T> e, ExpK<T> xk, int nxv, int nz, int64_t ls, const T
         vec_t r;
 #pragma unroll
         for (int v = 0; v < V; ++v) r[v] = saturation_point<T, MODE>(e, xk, vt[j][v], va[j][v]);
-#if CS2_SAT_NT_STORE
-        __builtin_nontemporal_store(r, reinterpret_cast<vec_t*>(qsat + int64_t(k0 + j) * ls + int64_t(cv) * V));
-#else
-        *reinterpret_cast<vec_t*>(qsat + int64_t(k0 + j) * ls + int64_t(cv) * V) = r;
-#endif
+        vec_t* dst = reinterpret_cast<vec_t*>(qsat + int64_t(k0 + j) * ls + int64_t(cv) * V);
+        if (keep && !CS2_SAT_NT_STORE) *dst = r;
+        else __builtin_nontemporal_store(r, dst);
     }
 }
 
@@ -72,26 +69,27 @@ int launch_saturation(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const
     const Ext<T> e = make_ext<T>(p);
     const ExpK<T> xk = make_expk<T>();
     constexpr int V = 16 / int(sizeof(T));
+    const int keep = qsat_fits_cache<T>(nz, ls) ? 1 : 0;
     const bool vec = nx % V == 0 && (ls * int64_t(sizeof(T))) % 16 == 0 && reinterpret_cast<uintptr_t>(ap) % 16 == 0 &&
                      reinterpret_cast<uintptr_t>(t) % 16 == 0 && reinterpret_cast<uintptr_t>(qsat) % 16 == 0;
     if (vec) {
         const int nxv = nx / V;
         const dim3 vgrid((nxv + kAuxBlock - 1) / kAuxBlock, (nz + kSatLPT - 1) / kSatLPT), vblock(kAuxBlock);
         if (p.LPHYLIN)
-            hipLaunchKernelGGL((saturation_vec_kernel<T, 0>), vgrid, vblock, 0, stream, e, xk, nxv, nz, ls, ap, t, qsat);
+            hipLaunchKernelGGL((saturation_vec_kernel<T, 0>), vgrid, vblock, 0, stream, e, xk, nxv, nz, ls, ap, t, qsat, keep);
         else if (p.KFLAG == 1)
-            hipLaunchKernelGGL((saturation_vec_kernel<T, 1>), vgrid, vblock, 0, stream, e, xk, nxv, nz, ls, ap, t, qsat);
+            hipLaunchKernelGGL((saturation_vec_kernel<T, 1>), vgrid, vblock, 0, stream, e, xk, nxv, nz, ls, ap, t, qsat, keep);
         else
-            hipLaunchKernelGGL((saturation_vec_kernel<T, 2>), vgrid, vblock, 0, stream, e, xk, nxv, nz, ls, ap, t, qsat);
+            hipLaunchKernelGGL((saturation_vec_kernel<T, 2>), vgrid, vblock, 0, stream, e, xk, nxv, nz, ls, ap, t, qsat, keep);
         return hipGetLastError() == hipSuccess ? 0 : -1;
     }
     const dim3 grid((nx + kAuxBlock - 1) / kAuxBlock, nz), block(kAuxBlock);
     if (p.LPHYLIN)
-        hipLaunchKernelGGL((saturation_kernel<T, 0>), grid, block, 0, stream, e, xk, nx, ls, ap, t, qsat);
+        hipLaunchKernelGGL((saturation_kernel<T, 0>), grid, block, 0, stream, e, xk, nx, ls, ap, t, qsat, keep);
     else if (p.KFLAG == 1)
-        hipLaunchKernelGGL((saturation_kernel<T, 1>), grid, block, 0, stream, e, xk, nx, ls, ap, t, qsat);
+        hipLaunchKernelGGL((saturation_kernel<T, 1>), grid, block, 0, stream, e, xk, nx, ls, ap, t, qsat, keep);
     else
-        hipLaunchKernelGGL((saturation_kernel<T, 2>), grid, block, 0, stream, e, xk, nx, ls, ap, t, qsat);
+        hipLaunchKernelGGL((saturation_kernel<T, 2>), grid, block, 0, stream, e, xk, nx, ls, ap, t, qsat, keep);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -66,12 +66,12 @@ template <typename T>
 int nl_impl(const char* fn, const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls, const T* const* in,
             const T* eta, T* const* out, double dt, void* stream) {
     if (int rc = check_common(fn, p, nx, nz, ls)) return rc;
+    if (nx == 0) return CLOUDSC2_OK;   // empty call: nothing to check or launch (zero-size tensors carry NULL pointers)
     if (int rc = check_ptrs(fn, "in", in, NL_NUM_IN)) return rc;
     if (int rc = check_ptrs(fn, "out", const_cast<const T* const*>(out), NL_NUM_OUT)) return rc;
     if (!eta) return fail(CLOUDSC2_E_ARG, "%s: eta is NULL", fn);
     if (p->ICALL != 0) return fail(CLOUDSC2_E_UNSUPPORTED, "%s: ICALL=%d (the reference implements ICALL == 0 only)", fn, p->ICALL);
     if (!(dt > 0.0)) return fail(CLOUDSC2_E_ARG, "%s: dt=%g must be > 0", fn, dt);
-    if (nx == 0) return CLOUDSC2_OK;
     return launched(fn, cs2::launch_nl<T>(*p, nx, nz, ls, in, eta, out, dt, static_cast<hipStream_t>(stream), nullptr,
                                           0.0, nullptr, nullptr));
 }
@@ -81,6 +81,7 @@ template <typename T>
 int nl_fused_impl(const char* fn, const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls, const T* const* in,
                   const T* const* in_i, double pf, T* qsat_out, const T* eta, T* const* out, double dt, void* stream) {
     if (int rc = check_common(fn, p, nx, nz, ls)) return rc;
+    if (nx == 0) return CLOUDSC2_OK;   // empty call: nothing to check or launch (zero-size tensors carry NULL pointers)
     if (int rc = check_ptrs(fn, "out", const_cast<const T* const*>(out), NL_NUM_OUT)) return rc;
     if (!in) return fail(CLOUDSC2_E_ARG, "%s: in is NULL", fn);
     if ((qsat_out != nullptr) == (in_i != nullptr))
@@ -94,7 +95,6 @@ int nl_fused_impl(const char* fn, const Cloudsc2Params* p, int32_t nx, int32_t n
     if (qsat_out && !p->LPHYLIN)
         return fail(CLOUDSC2_E_UNSUPPORTED, "%s: only the LPHYLIN form of saturation is available fused", fn);
     if (!(dt > 0.0)) return fail(CLOUDSC2_E_ARG, "%s: dt=%g must be > 0", fn, dt);
-    if (nx == 0) return CLOUDSC2_OK;
     return launched(fn, cs2::launch_nl<T>(*p, nx, nz, ls, in, eta, out, dt, static_cast<hipStream_t>(stream), in_i, pf,
                                           qsat_out, nullptr));
 }
@@ -105,6 +105,7 @@ int nl_taylor_impl(const char* fn, const Cloudsc2Params* p, int32_t nx, int32_t 
                    const T* const* in_i, double pf, const T* eta, const T* const* ref_out, double* partials, double dt,
                    void* stream) {
     if (int rc = check_common(fn, p, nx, nz, ls)) return rc;
+    if (nx == 0) return CLOUDSC2_OK;   // empty call: nothing to check or launch (zero-size tensors carry NULL pointers)
     if (int rc = check_ptrs(fn, "in", in, NL_NUM_IN)) return rc;
     if (int rc = check_ptrs(fn, "in_i", in_i, NL_NUM_IN)) return rc;
     if (int rc = check_ptrs(fn, "ref_out", ref_out, NL_NUM_OUT)) return rc;
@@ -112,7 +113,6 @@ int nl_taylor_impl(const char* fn, const Cloudsc2Params* p, int32_t nx, int32_t 
     if (!partials) return fail(CLOUDSC2_E_ARG, "%s: partials is NULL", fn);
     if (p->ICALL != 0) return fail(CLOUDSC2_E_UNSUPPORTED, "%s: ICALL=%d unsupported", fn, p->ICALL);
     if (!(dt > 0.0)) return fail(CLOUDSC2_E_ARG, "%s: dt=%g must be > 0", fn, dt);
-    if (nx == 0) return CLOUDSC2_OK;
     // the kernel only READS the reference outputs; the launcher's pointer pack is the mutable one
     T* refs[NL_NUM_OUT];
     for (int i = 0; i < NL_NUM_OUT; ++i) refs[i] = const_cast<T*>(ref_out[i]);
@@ -124,6 +124,7 @@ template <typename T>
 int tl_impl(const char* fn, const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls, const T* const* in,
             const T* const* in_i, const T* eta, T* const* out, T* const* out_i, double dt, void* stream) {
     if (int rc = check_common(fn, p, nx, nz, ls)) return rc;
+    if (nx == 0) return CLOUDSC2_OK;   // empty call: nothing to check or launch (zero-size tensors carry NULL pointers)
     if (int rc = check_ptrs(fn, "in", in, NL_NUM_IN)) return rc;
     if (int rc = check_ptrs(fn, "in_i", in_i, NL_NUM_IN)) return rc;
     if (int rc = check_ptrs(fn, "out", const_cast<const T* const*>(out), NL_NUM_OUT)) return rc;
@@ -132,7 +133,6 @@ int tl_impl(const char* fn, const Cloudsc2Params* p, int32_t nx, int32_t nz, int
     if (p->ICALL != 0) return fail(CLOUDSC2_E_UNSUPPORTED, "%s: ICALL=%d unsupported", fn, p->ICALL);
     if (!(dt > 0.0)) return fail(CLOUDSC2_E_ARG, "%s: dt=%g must be > 0", fn, dt);
     if (p->NLEV != nz) return fail(CLOUDSC2_E_ARG, "%s: NLEV=%d != nz=%d", fn, p->NLEV, nz);
-    if (nx == 0) return CLOUDSC2_OK;
     return launched(fn, cs2::launch_tl<T>(*p, nx, nz, ls, in, in_i, eta, out, out_i, dt, static_cast<hipStream_t>(stream)));
 }
 
@@ -140,6 +140,7 @@ template <typename T>
 int ad_impl(const char* fn, const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls, const T* const* in,
             const T* const* in_adj, const T* eta, T* const* out, T* const* out_adj, double dt, void* stream) {
     if (int rc = check_common(fn, p, nx, nz, ls)) return rc;
+    if (nx == 0) return CLOUDSC2_OK;   // empty call: nothing to check or launch (zero-size tensors carry NULL pointers)
     if (int rc = check_ptrs(fn, "in", in, NL_NUM_IN)) return rc;
     if (int rc = check_ptrs(fn, "in_adj", in_adj, NL_NUM_OUT)) return rc;
     if (int rc = check_ptrs(fn, "out", const_cast<const T* const*>(out), NL_NUM_OUT)) return rc;
@@ -148,7 +149,6 @@ int ad_impl(const char* fn, const Cloudsc2Params* p, int32_t nx, int32_t nz, int
     if (p->ICALL != 0) return fail(CLOUDSC2_E_UNSUPPORTED, "%s: ICALL=%d unsupported", fn, p->ICALL);
     if (!(dt > 0.0)) return fail(CLOUDSC2_E_ARG, "%s: dt=%g must be > 0", fn, dt);
     if (p->NLEV != nz) return fail(CLOUDSC2_E_ARG, "%s: NLEV=%d != nz=%d", fn, p->NLEV, nz);
-    if (nx == 0) return CLOUDSC2_OK;
     return launched(fn, cs2::launch_ad<T>(*p, nx, nz, ls, in, in_adj, eta, out, out_adj, dt, static_cast<hipStream_t>(stream)));
 }
 
@@ -156,8 +156,8 @@ template <typename T>
 int sat_impl(const char* fn, const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls, const T* ap, const T* t,
              T* qsat, void* stream) {
     if (int rc = check_common(fn, p, nx, nz, ls)) return rc;
+    if (nx == 0) return CLOUDSC2_OK;   // empty call: nothing to check or launch (zero-size tensors carry NULL pointers)
     if (!ap || !t || !qsat) return fail(CLOUDSC2_E_ARG, "%s: NULL field pointer", fn);
-    if (nx == 0) return CLOUDSC2_OK;
     return launched(fn, cs2::launch_saturation<T>(*p, nx, nz, ls, ap, t, qsat, static_cast<hipStream_t>(stream)));
 }
 
@@ -165,9 +165,9 @@ template <typename T>
 int inc_impl(const char* fn, const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls, const T* const* in,
              T* const* out, double f, void* stream) {
     if (int rc = check_common(fn, p, nx, nz, ls)) return rc;
+    if (nx == 0) return CLOUDSC2_OK;   // empty call: nothing to check or launch (zero-size tensors carry NULL pointers)
     if (int rc = check_ptrs(fn, "in", in, INC_NUM)) return rc;
     if (int rc = check_ptrs(fn, "out_i", const_cast<const T* const*>(out), INC_NUM)) return rc;
-    if (nx == 0) return CLOUDSC2_OK;
     return launched(fn, cs2::launch_increment<T>(*p, nx, nz, ls, in, out, f, static_cast<hipStream_t>(stream)));
 }
 
@@ -175,10 +175,10 @@ template <typename T>
 int per_impl(const char* fn, const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls, const T* const* in,
              const T* const* in_i, T* const* out, double f, void* stream) {
     if (int rc = check_common(fn, p, nx, nz, ls)) return rc;
+    if (nx == 0) return CLOUDSC2_OK;   // empty call: nothing to check or launch (zero-size tensors carry NULL pointers)
     if (int rc = check_ptrs(fn, "in", in, INC_NUM)) return rc;
     if (int rc = check_ptrs(fn, "in_i", in_i, INC_NUM)) return rc;
     if (int rc = check_ptrs(fn, "out", const_cast<const T* const*>(out), INC_NUM)) return rc;
-    if (nx == 0) return CLOUDSC2_OK;
     return launched(fn, cs2::launch_perturb<T>(nx, nz, ls, in, in_i, out, f, static_cast<hipStream_t>(stream)));
 }
 

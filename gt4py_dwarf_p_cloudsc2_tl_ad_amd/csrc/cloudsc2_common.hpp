@@ -232,6 +232,14 @@ __device__ __forceinline__ void ntstore(T* a, T v) {
     *a = v;
 #endif
 }
+// Producer-consumer residency of `qsat` (saturation -> cloudsc2_nl, run_nonlinear.py:117-118): default cache policy
+// on that one store / load pays when the field fits the 256 MB memory-side cache beside the streams passing through
+// (72 MB at 65 536 fp64 columns: saturation + NL 391 -> 370 us) and costs 3-4 % when it does not (289 MB at
+// 524 288 fp32 columns: 1 598 -> 1 662 us), so both launchers decide with the same rule.
+template <typename T>
+inline bool qsat_fits_cache(int nz, int64_t ls) {
+    return static_cast<uint64_t>(nz + 1) * static_cast<uint64_t>(ls) * sizeof(T) <= (uint64_t(128) << 20);
+}
 template <typename T>
 inline bool fits_u32_offsets(int nz, int64_t ls) {
     return static_cast<uint64_t>(nz + 1) * static_cast<uint64_t>(ls) * sizeof(T) <= 0xFFFFFFFFull;

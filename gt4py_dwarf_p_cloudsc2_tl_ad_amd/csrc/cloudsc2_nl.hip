@@ -55,7 +55,8 @@ struct NLIn {
 template <typename T>
 // `o` = byte offset of (level k, this lane's column); `lsb` = level stride in bytes.
 // SKIPQ: in_qsat is not read (the fused-saturation variant computes it).
-__device__ __forceinline__ NLIn<T> nl_load_impl(const CPtrs<T, NL_NUM_IN>& in, uint32_t lsb, uint32_t o, bool skipq) {
+__device__ __forceinline__ NLIn<T> nl_load_impl(const CPtrs<T, NL_NUM_IN>& in, uint32_t lsb, uint32_t o, bool skipq,
+                                                 bool keepq = false) {
     NLIn<T> x;
     x.ap = ldg(in.p[NL_IN_AP], o);
     x.aph1 = ldg(in.p[NL_IN_APH], o + lsb);
@@ -66,7 +67,8 @@ __device__ __forceinline__ NLIn<T> nl_load_impl(const CPtrs<T, NL_NUM_IN>& in, u
     x.q = ldg(in.p[NL_IN_Q], o);
     x.qi = ldg(in.p[NL_IN_QI], o);
     x.ql = ldg(in.p[NL_IN_QL], o);
-    x.qsat = skipq ? T(0.0) : ldg_keep(in.p[NL_IN_QSAT], o);   // just written by `saturation`: let it hit the cache
+    // in_qsat was just written by `saturation`: when the field fits the memory-side cache (keepq, launcher) let the load hit it
+    x.qsat = skipq ? T(0.0) : (keepq ? ldg_keep(in.p[NL_IN_QSAT], o) : ldg(in.p[NL_IN_QSAT], o));
     x.supsat = ldg(in.p[NL_IN_SUPSAT], o);
     x.t = ldg(in.p[NL_IN_T], o);
     x.tq = ldg(in.p[NL_IN_TND_CML_Q], o);
@@ -77,8 +79,8 @@ __device__ __forceinline__ NLIn<T> nl_load_impl(const CPtrs<T, NL_NUM_IN>& in, u
 }
 
 template <typename T, bool SKIPQ>
-__device__ __forceinline__ NLIn<T> nl_load(const CPtrs<T, NL_NUM_IN>& in, uint32_t lsb, uint32_t o) {
-    return nl_load_impl<T>(in, lsb, o, SKIPQ);
+__device__ __forceinline__ NLIn<T> nl_load(const CPtrs<T, NL_NUM_IN>& in, uint32_t lsb, uint32_t o, bool keepq = false) {
+    return nl_load_impl<T>(in, lsb, o, SKIPQ, keepq);
 }
 
 // perturbed_state (common/_stencils/perturbed_state.py:75-91) applied on the fly: x + f * x_i.
@@ -371,7 +373,7 @@ template <typename T, bool EVAP, bool LIN, bool PINK, int FUSE>
 __global__ void __launch_bounds__(kColBlock, (sizeof(T) == 4 ? CS2_F32_WAVES : 1))
 nl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, NL_NUM_IN> in, const T* __restrict__ eta,
           MPtrs<T, NL_NUM_OUT> out, T dt, CPtrs<T, NL_NUM_IN> in_i, T pf, T* __restrict__ qsat_out,
-          double* __restrict__ partials) {
+          double* __restrict__ partials, int keepq) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     T* s_eta = reinterpret_cast<T*>(smem_raw);
     T* s_scalm = s_eta + (nz + 1);
@@ -436,7 +438,7 @@ nl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
 #pragma unroll
     for (int j = 0; j < PD; ++j) {
         const uint32_t oj = colb + uint32_t(j < nz ? j : 0) * lsb;
-        buf[j] = nl_load<T, FUSE == 1>(in, lsb, oj);
+        buf[j] = nl_load<T, FUSE == 1>(in, lsb, oj, keepq != 0);
         if constexpr (PERT) bufi[j] = nl_load<T, false>(in_i, lsb, oj);
     }
     buf[PD] = buf[0];
@@ -449,7 +451,7 @@ nl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
             const int k = k0 + j;
             if (k < nz) {
                 if (k + PD < nz) {
-                    buf[(j + PD) % (PD + 1)] = nl_load<T, FUSE == 1>(in, lsb, o + uint32_t(PD) * lsb);
+                    buf[(j + PD) % (PD + 1)] = nl_load<T, FUSE == 1>(in, lsb, o + uint32_t(PD) * lsb, keepq != 0);
                     if constexpr (PERT)
                         bufi[(j + PD) % (PD + 1)] = nl_load<T, false>(in_i, lsb, o + uint32_t(PD) * lsb);
                 }
@@ -539,8 +541,9 @@ nl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
 #ifndef CS2_NL_PS_REUSE
 #define CS2_NL_PS_REUSE 0
 #endif
-// Cache policy of the DMA that carries in_qsat: default (0), not nt - `saturation` wrote the field just before
-// (run_nonlinear.py:117-118) and it is still in the 256 MB memory-side cache.  -1: same policy as the other inputs.
+// Cache policy of the DMA that carries in_qsat when the field fits the memory-side cache (`keepq`, see qsat_fits_cache):
+// default (0), not nt - `saturation` wrote the field just before (run_nonlinear.py:117-118).  -1: never, same policy
+// as the other inputs.
 #ifndef CS2_NL_QSAT_AUX
 #define CS2_NL_QSAT_AUX 0
 #endif
@@ -631,7 +634,7 @@ __device__ __forceinline__ void ring_read(uint32_t a, uint32_t ta, uint32_t tb, 
 template <typename T, bool EVAP, bool LIN, bool PINK, int RD, bool SATF>
 __global__ void __launch_bounds__(kColBlock, 1)
 nl_ring_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, NL_NUM_IN> in,
-               const T* __restrict__ eta, MPtrs<T, NL_NUM_OUT> out, T dt, T* __restrict__ qsat_out) {
+               const T* __restrict__ eta, MPtrs<T, NL_NUM_OUT> out, T dt, T* __restrict__ qsat_out, int keepq) {
     using G = RingGeom<T>;
     static_assert(kColBlock % 64 == 0 && RD >= 2, "whole waves, at least one level in flight");
     static_assert((RD - 1) * (G::NI + G::NSTORE) < 64, "vmcnt is a 6-bit counter");
@@ -726,7 +729,7 @@ nl_ring_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtr
 #pragma unroll
         for (int i = 0; i < G::NI; ++i) {
             // (the cache-policy operand must be a literal constant at each call site)
-            if (CS2_NL_QSAT_AUX >= 0 && i == NL_IN_QSAT / G::NPL)
+            if (CS2_NL_QSAT_AUX >= 0 && keepq && i == NL_IN_QSAT / G::NPL)   // uniform
                 __builtin_amdgcn_global_load_lds((glb_void_ptr)src[i],
                                                  (lds_void_ptr)(&smem_raw[ring0 + uint32_t(slot * G::SLOT + i * 1024)]),
                                                  16, 0, CS2_NL_QSAT_AUX >= 0 ? CS2_NL_QSAT_AUX : 0);
@@ -814,10 +817,11 @@ int launch_nl(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
     const ExpK<T> xk = make_expk<T>();
     if (!fits_u32_offsets<T>(nz, ls)) return -2;
     const int fuse = qsat_out ? 1 : (in_i ? (partials ? 3 : 2) : 0);
+    const int keepq = qsat_fits_cache<T>(nz, ls) ? 1 : 0;   // in_qsat: default cache policy only when the field fits
     if (fuse == 1 && !p.LPHYLIN) return -2;   // only the LPHYLIN form of `saturation` is fused
 #define CS2_NL_LAUNCH(EV, LN, FU)                                                                                 \
     hipLaunchKernelGGL((nl_kernel<T, EV, LN, sizeof(T) == 8, FU>), grid, block, smem, stream, e, kc, xk, nx, nz, \
-                       ls, ci, eta, co, tdt, cii, tpf, qsat_out, partials)
+                       ls, ci, eta, co, tdt, cii, tpf, qsat_out, partials, keepq)
 #define CS2_NL_FLAGS(FU)                                   \
     do {                                                   \
         if (evap && lin) CS2_NL_LAUNCH(true, true, FU);    \
@@ -871,7 +875,8 @@ int launch_nl(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
                 return -1;                                                                                           \
             attr_set[dev & 63] = rsmem;                                                                              \
         }                                                                                                            \
-        hipLaunchKernelGGL(kern, grid, block, rsmem, stream, e, kc, xk, nx, nz, ls, ci, eta, co, tdt, qsat_out);     \
+        hipLaunchKernelGGL(kern, grid, block, rsmem, stream, e, kc, xk, nx, nz, ls, ci, eta, co, tdt, qsat_out,      \
+                           keepq);                                                                                   \
     } while (0)
 #define CS2_NL_RING_FLAGS(RD, SF)                                          \
     do {                                                                   \

@@ -408,3 +408,31 @@ def test_config5_shard_fp32(gpu):
         small = storage.klayout(sub_out["out_" + m])[:nlev].cpu().numpy()
         assert_close(f"shard vs block out_{m}", big, small, np.float32, rtol_mul=1e-2)
         assert_close(f"shard out_{m}", big, want[m][:nlev], np.float32)
+
+
+def test_empty_calls_are_no_ops(gpu):
+    """Zero columns (an empty rank of a ragged partition): every stencil accepts zero-size storages and does nothing."""
+    import torch
+
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd import storage
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.stencils import INC, NL_IN, compile_stencil
+
+    nz = 137
+    ext = externals(NLEV=nz)
+    z = lambda: storage.zeros(0, nz, np.float64, gpu)  # noqa: E731
+    eta = torch.zeros(nz + 1, dtype=torch.float64, device=gpu)
+    com = dict(origin=(0, 0, 0), validate_args=True, exec_info=None)
+    compile_stencil("saturation", ext)(in_ap=z(), in_t=z(), out_qsat=z(), domain=(0, 1, nz), **com)
+    ins = {"in_" + n: z() for n in NL_IN}
+    ins_i = {"in_" + n + "_i": z() for n in NL_IN}
+    compile_stencil("cloudsc2_nl", ext)(**ins, **{"out_" + n: z() for n in NL_OUT}, in_eta=eta, dt=3600.0,
+                                         domain=(0, 1, nz + 1), **com)
+    compile_stencil("cloudsc2_tl", ext)(**ins, **ins_i, **{"out_" + n: z() for n in NL_OUT},
+                                         **{"out_" + n + "_i": z() for n in NL_OUT}, in_eta=eta, dt=3600.0,
+                                         domain=(0, 1, nz + 1), **com)
+    compile_stencil("cloudsc2_ad", ext)(**ins, **{"in_" + n + "_i": z() for n in NL_OUT},
+                                         **{"out_" + n: z() for n in NL_OUT}, **{"out_" + n + "_i": z() for n in NL_IN},
+                                         in_eta=eta, dt=3600.0, domain=(0, 1, nz + 1), **com)
+    compile_stencil("state_increment", {"IGNORE_SUPSAT": False})(
+        **{"in_" + n: z() for n in INC}, **{"out_" + n + "_i": z() for n in INC}, f=0.01, domain=(0, 1, nz + 1), **com)
+    torch.cuda.synchronize()

@@ -308,14 +308,22 @@ inline NLK<T> make_nlk(const Cloudsc2Params& p, double dt, bool evap) {
 // with one wave per SIMD a load-compare-load loop exposes the full HBM latency once per level (22 us of a 337 us
 // kernel, measured).  The loads of CH levels are therefore issued back to back and compared afterwards: 3 round
 // trips instead of 42.  (klo, khi) come from build_level_table; khi <= nz - 2, so level khi + 1 exists.
-template <typename T>
+// PERT: the state is read as x + pf * x_i (the fused perturbed_state variants), exactly as nl_perturb forms it.
+template <typename T, bool PERT = false>
 __device__ __forceinline__ T trpaus_prescan(const T* __restrict__ pt, const T* __restrict__ ptt, uint32_t lsb,
-                                            uint32_t colb, T dt, const T* s_eta, int klo, int khi) {
+                                            uint32_t colb, T dt, const T* s_eta, int klo, int khi,
+                                            const T* __restrict__ pt_i = nullptr, const T* __restrict__ ptt_i = nullptr,
+                                            T pf = T(0.0)) {
     T trpaus = T(0.1);
     if (klo > khi) return trpaus;
-    constexpr int CH = 16;
+    constexpr int CH = PERT ? 8 : 16;
     const uint32_t o0 = uint32_t(klo) * lsb + colb;
-    T tk = ldg(pt, o0) + dt * ldg(ptt, o0);
+    T t0 = ldg(pt, o0), tt0 = ldg(ptt, o0);
+    if constexpr (PERT) {
+        t0 = t0 + pf * ldg(pt_i, o0);
+        tt0 = tt0 + pf * ldg(ptt_i, o0);
+    }
+    T tk = t0 + dt * tt0;
     for (int k0 = klo; k0 <= khi; k0 += CH) {
         T a[CH], b[CH];
 #pragma unroll
@@ -324,6 +332,10 @@ __device__ __forceinline__ T trpaus_prescan(const T* __restrict__ pt, const T* _
             const uint32_t oj = uint32_t(kk) * lsb + colb;
             a[j] = ldg(pt, oj);
             b[j] = ldg(ptt, oj);
+            if constexpr (PERT) {
+                a[j] = a[j] + pf * ldg(pt_i, oj);
+                b[j] = b[j] + pf * ldg(ptt_i, oj);
+            }
         }
 #pragma unroll
         for (int j = 0; j < CH; ++j) {

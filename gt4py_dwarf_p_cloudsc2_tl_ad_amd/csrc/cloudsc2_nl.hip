@@ -408,7 +408,12 @@ nl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
 #endif
     const uint32_t colb = uint32_t(col) * uint32_t(sizeof(T));
 
-    const T trpaus = trpaus_prescan<T>(in.p[NL_IN_T], in.p[NL_IN_TND_CML_T], lsb, colb, dt, s_eta, klo, khi);
+    // everything the fused-perturbed variants read outside nl_load is perturbed here as well: the pre-scan's t and
+    // tnd_cml_t, aph at the top half level and at the surface
+    constexpr bool PERTURBED = FUSE == 2 || FUSE == 3;
+    const T trpaus = PERTURBED ? trpaus_prescan<T, true>(in.p[NL_IN_T], in.p[NL_IN_TND_CML_T], lsb, colb, dt, s_eta, klo,
+                                                         khi, in_i.p[NL_IN_T], in_i.p[NL_IN_TND_CML_T], pf)
+                               : trpaus_prescan<T>(in.p[NL_IN_T], in.p[NL_IN_TND_CML_T], lsb, colb, dt, s_eta, klo, khi);
     const CrhCol<T> crh = crh_setup<T>(trpaus);
 
     // :93-100
@@ -417,7 +422,11 @@ nl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
     c.sfl = T(0.0);
     c.covptot = T(0.0);
     c.aph_k = ldg(in.p[NL_IN_APH], colb);
-    const T aph_s = EVAP ? ldg(in.p[NL_IN_APH], uint32_t(nz) * lsb + colb) : T(1.0);
+    T aph_s = EVAP ? ldg(in.p[NL_IN_APH], uint32_t(nz) * lsb + colb) : T(1.0);
+    if constexpr (PERTURBED) {
+        c.aph_k = c.aph_k + pf * ldg(in_i.p[NL_IN_APH], colb);
+        if constexpr (EVAP) aph_s = aph_s + pf * ldg(in_i.p[NL_IN_APH], uint32_t(nz) * lsb + colb);
+    }
 
     if (live && FUSE != 3) {
         // top half level: no flux enters the column (:392-394; out_fpls*[0] written as 0, the

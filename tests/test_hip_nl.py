@@ -436,3 +436,53 @@ def test_empty_calls_are_no_ops(gpu):
     compile_stencil("state_increment", {"IGNORE_SUPSAT": False})(
         **{"in_" + n: z() for n in INC}, **{"out_" + n + "_i": z() for n in INC}, f=0.01, domain=(0, 1, nz + 1), **com)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("sw", [dict(), dict(LEVAPLS2=True)])
+def test_fused_perturbation_with_general_increments(gpu, sw):
+    """The fused perturbed variants must perturb EVERYTHING the stencil reads, also what it reads outside the level loop:
+    the tropopause pre-scan's t / tnd_cml_t, aph at the top half level and (evaporation block) at the surface.  With
+    increments proportional to the state none of that shows (the ordering t[k] > t[k+1] is scale-invariant, aph[0] = 0);
+    here the increments are random, of order one and aph[0] != 0, so the tropopause level moves in many columns.
+    `cloudsc2_nl_perturbed` == perturbed_state then cloudsc2_nl, and `cloudsc2_nl_taylor` sums the same differences."""
+    import torch
+
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd import storage
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.stencils import INC, compile_stencil, taylor_blocks
+
+    nx, nz, f2 = 640, 137, 1.0
+    ext = externals(**sw)
+    fields, eta, dt = nl_case(nx, ext=ext)
+    fields["in_aph"][0] = 150.0 + 10.0 * np.arange(nx) / nx            # a model top that is not at p = 0
+    rng = np.random.default_rng(17)
+    inc = {}
+    for k, v in fields.items():
+        inc[k + "_i"] = (v * rng.uniform(-0.02, 0.02, size=v.shape)).astype(v.dtype)
+    inc["in_t_i"] = rng.normal(0.0, 2.5, size=fields["in_t"].shape) * (fields["in_t"] != 0)      # +-2.5 K: moves trpaus
+    inc["in_aph_i"][0] = 3.0
+    dev = to_device({**fields, **inc}, gpu)
+    eta_d = torch.as_tensor(eta, device=gpu)
+    com = dict(origin=(0, 0, 0), domain=(nx, 1, nz + 1), validate_args=True, exec_info=None)
+    pert = {"out_" + n: storage.zeros(nx, nz, np.float64, gpu) for n in INC}
+    compile_stencil("perturbed_state", {})(**{"in_" + n: dev["in_" + n] for n in INC},
+                                            **{"in_" + n + "_i": dev["in_" + n + "_i"] for n in INC}, **pert, f=f2, **com)
+    nl = compile_stencil("cloudsc2_nl", ext)
+    outs = {"out_" + n: storage.zeros(nx, nz, np.float64, gpu) for n in NL_OUT}
+    nl(**{"in_" + n: pert["out_" + n] for n in INC}, **outs, in_eta=eta_d, dt=dt, **com)
+    ref = {"out_" + n: storage.zeros(nx, nz, np.float64, gpu) for n in NL_OUT}
+    nl(**{k: v for k, v in dev.items() if not k.endswith("_i")}, **ref, in_eta=eta_d, dt=dt, **com)
+    # the perturbation must really move the tropopause somewhere, or this test proves nothing
+    moved = (storage.klayout(outs["out_clc"]) != storage.klayout(ref["out_clc"])).any(dim=0).float().mean()
+    assert float(moved) > 0.5
+    outs2 = {"out_" + n: storage.zeros(nx, nz, np.float64, gpu) for n in NL_OUT}
+    compile_stencil("cloudsc2_nl_perturbed", ext)(**dev, **outs2, in_eta=eta_d, f=f2, dt=dt, **com)
+    for n in NL_OUT:
+        assert torch.equal(outs2["out_" + n], outs["out_" + n]), n
+    part = torch.empty((taylor_blocks(nx), len(NL_OUT)), dtype=torch.float64, device=gpu)
+    compile_stencil("cloudsc2_nl_taylor", ext)(**dev, **{"ref_" + n: ref["out_" + n] for n in NL_OUT},
+                                                out_partials=part, in_eta=eta_d, f=f2, dt=dt, **com)
+    torch.cuda.synchronize()
+    got = part.sum(dim=0).cpu().numpy()
+    want = np.array([float((outs["out_" + n].double() - ref["out_" + n].double()).sum()) for n in NL_OUT])
+    mag = np.array([float((outs["out_" + n].double() - ref["out_" + n].double()).abs().sum()) for n in NL_OUT])
+    assert np.all(np.abs(got - want) <= 1e-12 * mag + 1e-300), (got, want)

@@ -163,6 +163,28 @@ def main():
             ev[f"{tag}_out_{n}"] = f["out_" + n]
         for n in NL_IN:
             ev[f"{tag}_out_{n}_i"] = f["out_" + n + "_i"]
+    # ---- default switches, driver timestep, but GENERAL data: every input field gets its own random increment
+    # (signs included, +-0.3 K on t) and the adjoint is forced with ten independent random fields - the vectors of the
+    # first file use `state_increment`'s proportional increments, under which many TL / AD terms cancel or vanish
+    rng = np.random.default_rng(SEED + 1)
+    for n in NL_IN:
+        ev[f"gen_{n}_i"] = ins["in_" + n] * rng.uniform(-0.02, 0.02, size=ins["in_" + n].shape)
+    ev["gen_t_i"] = rng.normal(0.0, 0.3, size=ins["in_t"].shape) * (ins["in_t"] != 0)
+    for tag, e in (("tl_gen", ext), ("tl_gen_noreg", {**ext, "LREGCL": False})):
+        f = run_tl(e, "gen", src=ev)
+        for n in NL_OUT:
+            ev[f"{tag}_out_{n}"] = f["out_" + n]
+            ev[f"{tag}_out_{n}_i"] = f["out_" + n + "_i"]
+    for n in NL_OUT:
+        scale = max(float(np.abs(out[f"nl_out_{n}"]).max()), 1e-30) if n != "covptot" else 1.0
+        ev[f"genf_{n}"] = rng.normal(0.0, 1.0, size=(NZ + 1, NX)) * scale
+        ev[f"genf_{n}"][NZ if n in ("clc", "covptot", "tnd_q", "tnd_qi", "tnd_ql", "tnd_t") else NZ + 1:] = 0.0
+    for tag, e in (("ad_gen", ext), ("ad_gen_noreg", {**ext, "LREGCL": False})):
+        f = run_ad(e, {n: ev[f"genf_{n}"] for n in NL_OUT})
+        for n in NL_OUT:
+            ev[f"{tag}_out_{n}"] = f["out_" + n]
+        for n in NL_IN:
+            ev[f"{tag}_out_{n}_i"] = f["out_" + n + "_i"]
     path = os.path.join(HERE, "reference_exec_evap.npz")
     np.savez_compressed(path, **ev)
     print(path, len(ev), "arrays", os.path.getsize(path) // 1024, "KiB")

@@ -328,3 +328,49 @@ def test_evaporation_block_fp32_instantiations(gpu, kind):
         assert_close(f"{kind}-evap fp32 out_{n}", got[n][:k], want[n][:k], np.float32)
     for n, v in outs_i.items():
         assert np.isfinite(v).all(), n
+
+
+@pytest.mark.parametrize("regcl", [True, False])
+def test_tl_with_general_increments(gpu, regcl):
+    """Increments proportional to the state (what `state_increment` produces, and what most tests above use) make many TL
+    terms cancel - a uniform 1 % scaling is nearly a symmetry of the scheme.  Here every input field gets its own random
+    increment (sign included) at the driver's dt = 3600 s, default switches, each column judged on its own scale."""
+    nx = 512
+    ext = externals(NLEV=137, LREGCL=regcl)
+    fields, eta, dt = nl_case(nx, ext=ext, seed=31)
+    rng = np.random.default_rng(23)
+    fi = {}
+    for k, v in fields.items():
+        fi[k + "_i"] = v * rng.uniform(-0.02, 0.02, size=v.shape)
+    fi["in_t_i"] = rng.normal(0.0, 0.3, size=fields["in_t"].shape) * (fields["in_t"] != 0)
+    want, want_i = run_oracle_tl(fields, fi, eta, dt, ext)
+    got, got_i = run_hip_tl(fields, fi, eta, dt, ext, gpu, nx, 137)
+    for n in NL_OUT:
+        k = nlev_of(n, 137)
+        _assert_close_by_column(f"tl general out_{n}", got[n][:k], want[n][:k], 1e-9)
+        _assert_close_by_column(f"tl general out_{n}_i", got_i[n][:k], want_i[n][:k], 1e-8)
+
+
+@pytest.mark.parametrize("flags", [dict(), dict(LREGCL=False), dict(AD_TRAJ_FIX=1)])
+def test_ad_with_general_forcing(gpu, flags):
+    """Adjoint forcings that come out of a TL run with proportional increments leave whole paths of cloudsc2_ad nearly
+    unexercised (in_clc_i is rounding noise there, in_covptot_i is zero).  Here all ten forcing fields are independent
+    random fields of the size of the corresponding NL output; every adjoint output is judged per column."""
+    nx = 512
+    ext = externals(NLEV=137, **flags)
+    fields, eta, dt = nl_case(nx, ext=ext, seed=37)
+    nl = run_oracle_nl(fields, eta, dt, ext)
+    rng = np.random.default_rng(29)
+    forcing = {}
+    for n in NL_OUT:
+        scale = max(float(np.abs(nl[n]).max()), 1e-30) if n != "covptot" else 1.0
+        forcing[n] = rng.normal(0.0, 1.0, size=nl[n].shape) * scale
+        forcing[n][nlev_of(n, 137):] = 0.0
+    want, want_i = run_oracle_ad(fields, forcing, eta, dt, ext)
+    got, got_i = run_hip_ad(fields, forcing, eta, dt, ext, gpu, nx, 137)
+    for n in NL_OUT:
+        k = nlev_of(n, 137)
+        _assert_close_by_column(f"ad general out_{n}", got[n][:k], want[n][:k], 1e-9)
+    for n in NL_IN:
+        k = 138 if n in ("aph", "lu") else 137
+        _assert_close_by_column(f"ad general out_{n}_i{flags}", got_i[n][:k], want_i[n][:k], 1e-7)

@@ -114,6 +114,34 @@ def test_oracle_ad_evaporation_matches_reference_source(gold, gold_evap, tag, fl
         assert (np.abs(oi[n] - want) <= tol * scale).all(), (tag, n, np.abs(oi[n] - want).max())
 
 
+@pytest.mark.parametrize("tag,flags", [("tl_gen", {}), ("tl_gen_noreg", dict(LREGCL=False))])
+def test_oracle_tl_general_increments_bit_exact(gold, gold_evap, tag, flags):
+    """Default switches, dt = 3600 s, every input with its own random increment (signs included): the vectors of the
+    first file use proportional increments, under which many TL terms cancel."""
+    _, fields, eta, dt = gold
+    ev, _, _ = gold_evap
+    fi = {"in_" + n + "_i": ev[f"gen_{n}_i"] for n in NL_IN}
+    o, oi = run_oracle_tl(fields, fi, eta, dt, externals(NLEV=NZ, **flags))
+    for n in NL_OUT:
+        assert np.array_equal(o[n], ev[f"{tag}_out_{n}"]), (tag, n)
+        assert np.array_equal(oi[n], ev[f"{tag}_out_{n}_i"]), (tag, n + "_i")
+    assert np.abs(ev[f"{tag}_out_clc_i"]).max() > 1e-3           # a real signal, not rounding noise
+
+
+@pytest.mark.parametrize("tag,flags", [("ad_gen", {}), ("ad_gen_noreg", dict(LREGCL=False))])
+def test_oracle_ad_general_forcing_matches_reference_source(gold, gold_evap, tag, flags):
+    _, fields, eta, dt = gold
+    ev, _, _ = gold_evap
+    forcing = {n: ev[f"genf_{n}"] for n in NL_OUT}
+    o, oi = run_oracle_ad(fields, forcing, eta, dt, externals(NLEV=NZ, **flags))
+    for n in NL_OUT:
+        assert np.array_equal(o[n], ev[f"{tag}_out_{n}"]), (tag, n)
+    for n in NL_IN:
+        want = ev[f"{tag}_out_{n}_i"]
+        scale = np.abs(want).max(axis=0, keepdims=True)
+        assert (np.abs(oi[n] - want) <= 1e-12 * scale).all(), (tag, n, np.abs(oi[n] - want).max())
+
+
 def test_oracle_increment_and_perturbation_bit_exact(gold):
     g, fields, _, _ = gold
     st = {n: g["in_" + n] for n in INC}
@@ -213,6 +241,38 @@ def test_hip_ad_evaporation_matches_reference_source(gpu, gold, gold_evap, tag, 
         k = 138 if n in ("aph", "lu") else 137
         # out_lu_i: see test_oracle_ad_evaporation_matches_reference_source (cancellation inside a_clc)
         _close_by_column(f"{tag} out_{n}_i", got_i[n][:k], ev[f"{tag}_out_{n}_i"][:k], 1e-4 if n == "lu" else 1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,flags", [("tl_gen", {}), ("tl_gen_noreg", dict(LREGCL=False))])
+def test_hip_tl_general_increments_match_reference_source(gpu, gold, gold_evap, tag, flags):
+    from test_hip_tl_ad import run_hip_tl
+
+    _, fields, eta, dt = gold
+    ev, _, _ = gold_evap
+    fi = {"in_" + n + "_i": ev[f"gen_{n}_i"] for n in NL_IN}
+    got, got_i = run_hip_tl(fields, fi, eta, dt, externals(NLEV=NZ, **flags), gpu, fields["in_ap"].shape[1], NZ)
+    for n in NL_OUT:
+        k = nlev_of(n, NZ)
+        _close_by_column(f"{tag} out_{n}", got[n][:k], ev[f"{tag}_out_{n}"][:k], 1e-9)
+        _close_by_column(f"{tag} out_{n}_i", got_i[n][:k], ev[f"{tag}_out_{n}_i"][:k], 1e-8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,flags", [("ad_gen", {}), ("ad_gen_noreg", dict(LREGCL=False))])
+def test_hip_ad_general_forcing_matches_reference_source(gpu, gold, gold_evap, tag, flags):
+    from test_hip_tl_ad import run_hip_ad
+
+    _, fields, eta, dt = gold
+    ev, _, _ = gold_evap
+    forcing = {n: ev[f"genf_{n}"] for n in NL_OUT}
+    got, got_i = run_hip_ad(fields, forcing, eta, dt, externals(NLEV=NZ, **flags), gpu, fields["in_ap"].shape[1], NZ)
+    for n in NL_OUT:
+        k = nlev_of(n, NZ)
+        _close_by_column(f"{tag} out_{n}", got[n][:k], ev[f"{tag}_out_{n}"][:k], 1e-9)
+    for n in NL_IN:
+        k = 138 if n in ("aph", "lu") else 137
+        _close_by_column(f"{tag} out_{n}_i", got_i[n][:k], ev[f"{tag}_out_{n}_i"][:k], 1e-7)
 
 
 @pytest.mark.gpu

@@ -374,3 +374,26 @@ def test_ad_with_general_forcing(gpu, flags):
     for n in NL_IN:
         k = 138 if n in ("aph", "lu") else 137
         _assert_close_by_column(f"ad general out_{n}_i{flags}", got_i[n][:k], want_i[n][:k], 1e-7)
+
+
+def test_symmetry_with_general_increments(gpu):
+    """<TL dx, TL dx> == <dx, AD TL dx> for an arbitrary dx (every field its own random increment, signs included;
+    supsat excluded as in the reference's test because of quirk Q7), not only for the proportional increments of the
+    reference's symmetry test: with AD_TRAJ_FIX the adjoint is the transpose of TL in every column."""
+    nx = 512
+    ext = externals(NLEV=137, AD_TRAJ_FIX=1)
+    fields, eta, dt = nl_case(nx, seed=41)
+    rng = np.random.default_rng(43)
+    fi = {k + "_i": v * rng.uniform(-0.02, 0.02, size=v.shape) for k, v in fields.items()}
+    fi["in_t_i"] = rng.normal(0.0, 0.3, size=fields["in_t"].shape) * (fields["in_t"] != 0)
+    fi["in_supsat_i"] = np.zeros_like(fields["in_supsat"])
+    _, tl_i = run_hip_tl(fields, fi, eta, dt, ext, gpu, nx, 137)
+    for n in NL_OUT:
+        tl_i[n][nlev_of(n, 137):] = 0.0
+    _, ad_i = run_hip_ad(fields, tl_i, eta, dt, ext, gpu, nx, 137)
+    for n in NL_IN:
+        ad_i[n][(138 if n in ("aph", "lu") else 137):] = 0.0
+    norm1, norm2, norm3 = symmetry_norm3(tl_i, fi, ad_i)
+    assert (norm1 > 0).all()
+    assert norm3.max() < 1e4, (norm3.max(), int(np.argmax(norm3)))
+    print(f"symmetry with general increments: max error {norm3.max():.3e} x eps")

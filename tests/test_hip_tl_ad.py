@@ -397,3 +397,39 @@ def test_symmetry_with_general_increments(gpu):
     assert (norm1 > 0).all()
     assert norm3.max() < 1e4, (norm3.max(), int(np.argmax(norm3)))
     print(f"symmetry with general increments: max error {norm3.max():.3e} x eps")
+
+
+def test_taylor_with_general_increments(gpu):
+    """TL against finite differences of NL for an arbitrary dx (the reference's Taylor protocol and scoring, but every
+    field with its own random increment), the perturbed NL runs through the fused `cloudsc2_nl_perturbed` kernel."""
+    import torch
+
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd import storage
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.stencils import compile_stencil
+
+    nx, nz = 2048, 137
+    ext = externals(NLEV=nz, LREGCL=False)                # no regularisation in the Taylor test (validation.py:84-85)
+    fields, eta, dt = nl_case(nx, seed=47)
+    rng = np.random.default_rng(53)
+    fi = {k + "_i": v * rng.uniform(-0.02, 0.02, size=v.shape) for k, v in fields.items()}
+    fi["in_t_i"] = rng.normal(0.0, 0.3, size=fields["in_t"].shape) * (fields["in_t"] != 0)
+    nl0, tl_i = run_hip_tl(fields, fi, eta, dt, ext, gpu, nx, nz)
+    dev = to_device({**fields, **fi}, gpu)
+    eta_d = torch.as_tensor(eta, device=gpu)
+    nlp = compile_stencil("cloudsc2_nl_perturbed", ext)
+    outs = {"out_" + n: storage.zeros(nx, nz, np.float64, gpu) for n in NL_OUT}
+
+    def perturbed(f2):
+        nlp(**dev, **outs, in_eta=eta_d, f=f2, dt=dt, origin=(0, 0, 0), domain=(nx, 1, nz + 1), validate_args=True,
+            exec_info=None)
+        torch.cuda.synchronize()
+        return {n: storage.klayout(outs["out_" + n]).cpu().numpy() for n in NL_OUT}
+
+    for n in NL_OUT:            # rows a stencil does not write are not part of the sums
+        nl0[n][nlev_of(n, nz):] = 0.0
+        tl_i[n][nlev_of(n, nz):] = 0.0
+    f2s = [10.0 ** -(i + 1) for i in range(10)]
+    norms = taylor_norms(nl0, perturbed, tl_i, f2s)
+    ok, msg = taylor_verdict(norms)
+    print("taylor norms (general increments):", " ".join(f"{x:.8f}" for x in norms), msg)
+    assert ok, (norms, msg)

@@ -433,3 +433,52 @@ def test_taylor_with_general_increments(gpu):
     ok, msg = taylor_verdict(norms)
     print("taylor norms (general increments):", " ".join(f"{x:.8f}" for x in norms), msg)
     assert ok, (norms, msg)
+
+
+def test_tl_ad_on_strided_column_windows(gpu):
+    """lev_stride > nx: TL and AD on a column window of wider storages (a rank's shard addressed in place) give the
+    bits of the same columns copied into contiguous storages; columns outside the window are not touched."""
+    import torch
+
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd import storage
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.stencils import compile_stencil
+
+    nx, nz, W, c0 = 192, 137, 300, 37
+    ext = externals(NLEV=nz)
+    fields, eta, dt = nl_case(nx, seed=59)
+    fi = increments(fields, 0.01, ignore_supsat=True)
+    eta_d = torch.as_tensor(eta, device=gpu)
+    tdt = storage.torch_dtype(np.float64)
+
+    def wide(v=None):
+        t = torch.full((nz + 1, W), 7.0, dtype=tdt, device=gpu)
+        if v is not None:
+            t[:, c0:c0 + nx] = torch.as_tensor(v, device=gpu)
+        return t
+
+    def win(t):
+        return storage.logical_view(t[:, c0:c0 + nx])
+
+    com = dict(in_eta=eta_d, dt=dt, origin=(0, 0, 0), domain=(nx, 1, nz + 1), validate_args=True, exec_info=None)
+    # contiguous reference calls
+    dev = to_device({**fields, **fi}, gpu)
+    tl_c = {"out_" + n + s: storage.zeros(nx, nz, np.float64, gpu) for n in NL_OUT for s in ("", "_i")}
+    compile_stencil("cloudsc2_tl", ext)(**dev, **tl_c, **com)
+    frc = {"in_" + n + "_i": tl_c["out_" + n + "_i"] for n in NL_OUT}
+    ad_c = {"out_" + n: storage.zeros(nx, nz, np.float64, gpu) for n in NL_OUT}
+    ad_c.update({"out_" + n + "_i": storage.zeros(nx, nz, np.float64, gpu) for n in NL_IN})
+    compile_stencil("cloudsc2_ad", ext)(**{k: v for k, v in dev.items() if not k.endswith("_i")}, **frc, **ad_c, **com)
+    # the same through windows of wide storages
+    wi = {k: wide(v) for k, v in {**fields, **fi}.items()}
+    tl_w = {k: wide() for k in tl_c}
+    compile_stencil("cloudsc2_tl", ext)(**{k: win(v) for k, v in wi.items()}, **{k: win(v) for k, v in tl_w.items()}, **com)
+    frc_w = {"in_" + n + "_i": win(tl_w["out_" + n + "_i"]) for n in NL_OUT}
+    ad_w = {k: wide() for k in ad_c}
+    compile_stencil("cloudsc2_ad", ext)(**{k: win(v) for k, v in wi.items() if not k.endswith("_i")}, **frc_w,
+                                         **{k: win(v) for k, v in ad_w.items()}, **com)
+    torch.cuda.synchronize()
+    for name, c, w in [(k, tl_c[k], tl_w[k]) for k in tl_c] + [(k, ad_c[k], ad_w[k]) for k in ad_c]:
+        half = name.replace("out_", "").replace("_i", "") in ("fhpsl", "fhpsn", "fplsl", "fplsn", "aph", "lu")
+        rows = nz + 1 if half and not name.startswith("out_tnd") else nz
+        assert torch.equal(storage.klayout(c)[:rows], w[:rows, c0:c0 + nx]), name
+        assert bool((w[:, :c0] == 7.0).all()) and bool((w[:, c0 + nx:] == 7.0).all()), name

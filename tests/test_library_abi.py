@@ -104,3 +104,34 @@ def test_size_limits_and_empty_calls(hip_lib):
                      ("cloudsc2_state_increment_f64", (ins, ins_i, 0.01, None)),
                      ("cloudsc2_perturbed_state_f64", (ins, ins_i, ins, 0.001, None))):
         assert getattr(hip_lib, fn)(ctypes.byref(p), 0, 137, 64, *args) == 0, fn
+
+
+def test_stencil_call_signature_errors(hip_lib):
+    """The stencil objects keep the GT4Py call discipline: keyword arguments by gtscript parameter name, scalars present,
+    nothing unknown, `tmp_*` scratch arguments accepted and ignored, mismatched storages refused - all before any launch."""
+    import torch
+
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd import storage
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.stencils import INC, NL_IN, NL_OUT, compile_stencil
+
+    nx, nz = 8, 4
+    z = lambda: storage.zeros(nx, nz, torch.float64, "cpu")  # noqa: E731
+    eta = torch.zeros(nz + 1, dtype=torch.float64)
+    nl = compile_stencil("cloudsc2_nl", {"NLEV": nz})
+    good = {**{"in_" + n: z() for n in NL_IN}, **{"out_" + n: z() for n in NL_OUT}}
+    com = dict(in_eta=eta, origin=(0, 0, 0), domain=(nx, 1, nz + 1), validate_args=True, exec_info=None)
+    with pytest.raises(TypeError, match="in_qsat"):
+        nl(**{k: v for k, v in good.items() if k != "in_qsat"}, dt=3600.0, **com)
+    with pytest.raises(TypeError, match="dt"):
+        nl(**good, **com)
+    with pytest.raises(TypeError, match="unexpected"):
+        nl(**good, dt=3600.0, in_bogus=z(), **com)
+    with pytest.raises(ValueError, match="origin"):
+        nl(**good, dt=3600.0, **{**com, "origin": (1, 0, 0)})
+    # scratch arguments of the gtscript signature are accepted (and never touched): the call gets as far as the device check
+    with pytest.raises(ValueError, match="GPU"):
+        nl(**good, dt=3600.0, tmp_aph_s=None, tmp_covptot=None, tmp_rfl=None, tmp_sfl=None, tmp_trpaus=None, **com)
+    inc = compile_stencil("state_increment", {"IGNORE_SUPSAT": True})
+    with pytest.raises(TypeError, match="'f'"):
+        inc(**{"in_" + n: z() for n in INC}, **{"out_" + n + "_i": z() for n in INC}, origin=(0, 0, 0),
+            domain=(nx, 1, nz + 1), validate_args=True, exec_info=None)

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Shape / switch fuzz of the HIP kernels against the NumPy oracle (dev tool, run on the GPU box):
+random nx (whole waves, ragged, tiny), random nz (3 .. 80: very short columns, windows longer than the levels above
+them, no window at all), both precisions, random externals switches; NL, TL and AD each time.
+   python profiles/fuzz_shapes.py [cases] [seed]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    import numpy as np
+    import torch
+
+    from helpers import (NL_IN, NL_OUT, assert_close, externals, increments, nl_case, nlev_of, run_oracle_ad,
+                         run_oracle_nl, run_oracle_tl)
+    from test_hip_nl import run_hip_nl
+    from test_hip_tl_ad import run_hip_ad, run_hip_tl
+
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    gpu = torch.device("cuda:0")
+    done = 0
+    for it in range(cases):
+        nx = int(rng.choice([1, 2, 63, 64, 65, 128, 192, 255, 256, 257, 320, 448, 700]))
+        nz = int(rng.choice([3, 4, 5, 9, 17, 33, 60, 80]))
+        dtype = np.float64 if rng.random() < 0.6 else np.float32
+        sw = {}
+        if rng.random() < 0.35:
+            sw["LEVAPLS2"] = True
+        if rng.random() < 0.2:
+            sw["LDRAIN1D"] = True
+        if rng.random() < 0.25:
+            sw["LPHYLIN"] = False
+        reg = bool(rng.random() < 0.5)
+        ext = externals(NLEV=nz, LREGCL=reg, **sw)
+        fields, eta, dt = nl_case(nx, nz=nz, dtype=dtype, seed=int(rng.integers(1, 10 ** 6)), ext=ext)
+        tag = f"nx={nx} nz={nz} {np.dtype(dtype).name} {sw} reg={reg}"
+        # natural magnitudes: a tendency that is pure cancellation noise (1e-16) in a 6-point case is not a signal
+        qs, ts = float(np.abs(fields["in_q"]).max()) / dt, float(np.abs(fields["in_t"]).max()) / dt
+        floor = {"clc": 1.0, "covptot": 1.0, "tnd_q": qs, "tnd_ql": qs, "tnd_qi": qs, "tnd_t": ts,
+                 "fplsl": 1e-9, "fplsn": 1e-9, "fhpsl": 2.5e-3, "fhpsn": 2.5e-3}
+        floor = {k: 1e-3 * v for k, v in floor.items()}
+        want = run_oracle_nl(fields, eta, dt, ext)
+        got = run_hip_nl(fields, eta, dt, ext, gpu, nx, nz)
+        for n in NL_OUT:
+            k = nlev_of(n, nz)
+            partner = {"fplsl": "fplsn", "fplsn": "fplsl", "fhpsl": "fhpsn", "fhpsn": "fhpsl"}.get(n, n)
+            scale = max(float(np.abs(want[n]).max()), float(np.abs(want[partner]).max()), floor[n])
+            assert_close(f"NL {n} {tag}", got[n][:k], want[n][:k], dtype, scale=scale)
+        if dtype == np.float64 and not (sw.get("LEVAPLS2") or sw.get("LDRAIN1D")):   # TL / AD: well-conditioned cases
+            fi = increments(fields, 0.01, ignore_supsat=True)
+            wt, wti = run_oracle_tl(fields, fi, eta, dt, ext)
+            gt, gti = run_hip_tl(fields, fi, eta, dt, ext, gpu, nx, nz)
+            for n in NL_OUT:
+                k = nlev_of(n, nz)
+                assert_close(f"TL {n} {tag}", gt[n][:k], wt[n][:k], dtype)
+                assert_close(f"TL {n}_i {tag}", gti[n][:k], wti[n][:k], dtype, rtol_mul=100.0)
+            wa, wai = run_oracle_ad(fields, wti, eta, dt, ext)
+            ga, gai = run_hip_ad(fields, wti, eta, dt, ext, gpu, nx, nz)
+            for n in NL_IN:
+                k = nz + 1 if n in ("aph", "lu") else nz
+                assert_close(f"AD {n}_i {tag}", gai[n][:k], wai[n][:k], dtype, rtol_mul=1000.0)
+        done += 1
+        if it % 10 == 9:
+            print(f"{it + 1} cases ok (last: {tag})", flush=True)
+    print(f"fuzz: {done} cases agree with the oracle")
+
+
+if __name__ == "__main__":
+    main()

@@ -20,6 +20,14 @@ def main():
     from test_hip_nl import run_hip_nl
     from test_hip_tl_ad import run_hip_ad, run_hip_tl
 
+    def by_column(name, got, want, tol):
+        assert not np.isnan(got).any(), name
+        scale = np.abs(want).max(axis=0, keepdims=True)
+        floor = 1e-12 * float(np.abs(want).max())          # columns that carry nothing are judged on the field's scale
+        err = np.abs(got - want)
+        bad = err > tol * np.maximum(scale, floor) + np.finfo(np.float64).tiny
+        assert not bad.any(), f"{name}: worst {np.max(err / (np.maximum(scale, floor) + 1e-300)):.2e} of the column scale"
+
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     gpu = torch.device("cuda:0")
@@ -51,19 +59,38 @@ def main():
             partner = {"fplsl": "fplsn", "fplsn": "fplsl", "fhpsl": "fhpsn", "fhpsn": "fhpsl"}.get(n, n)
             scale = max(float(np.abs(want[n]).max()), float(np.abs(want[partner]).max()), floor[n])
             assert_close(f"NL {n} {tag}", got[n][:k], want[n][:k], dtype, scale=scale)
-        if dtype == np.float64 and not (sw.get("LEVAPLS2") or sw.get("LDRAIN1D")):   # TL / AD: well-conditioned cases
-            fi = increments(fields, 0.01, ignore_supsat=True)
-            wt, wti = run_oracle_tl(fields, fi, eta, dt, ext)
-            gt, gti = run_hip_tl(fields, fi, eta, dt, ext, gpu, nx, nz)
+        evap = bool(sw.get("LEVAPLS2") or sw.get("LDRAIN1D"))
+        if dtype == np.float64 and not evap:
+            # TL with general increments, AD with general forcings, every column on its own scale.  (The evaporation
+            # block's perturbations are ill-conditioned by construction - the reference's dt**2 quirk, DESIGN 3.3 - and on
+            # the coarse random grids of this fuzz even at dt = 60 s; tests/ pins that block on the 137-level grid.)
+            tdt = dt
+            fi = {k + "_i": v * rng.uniform(-0.02, 0.02, size=v.shape) for k, v in fields.items()}
+            fi["in_t_i"] = rng.normal(0.0, 0.3, size=fields["in_t"].shape) * (fields["in_t"] != 0)
+            fi["in_supsat_i"] = np.zeros_like(fields["in_supsat"])
+            wt, wti = run_oracle_tl(fields, fi, eta, tdt, ext)
+            gt, gti = run_hip_tl(fields, fi, eta, tdt, ext, gpu, nx, nz)
             for n in NL_OUT:
                 k = nlev_of(n, nz)
-                assert_close(f"TL {n} {tag}", gt[n][:k], wt[n][:k], dtype)
-                assert_close(f"TL {n}_i {tag}", gti[n][:k], wti[n][:k], dtype, rtol_mul=100.0)
-            wa, wai = run_oracle_ad(fields, wti, eta, dt, ext)
-            ga, gai = run_hip_ad(fields, wti, eta, dt, ext, gpu, nx, nz)
+                partner = {"fplsl": "fplsn", "fplsn": "fplsl", "fhpsl": "fhpsn", "fhpsn": "fhpsl"}.get(n, n)
+                sc = max(float(np.abs(wt[n]).max()), float(np.abs(wt[partner]).max()), floor[n])
+                assert_close(f"TL {n} {tag}", gt[n][:k], wt[n][:k], dtype, scale=sc)
+                by_column(f"TL {n}_i {tag}", gti[n][:k], wti[n][:k], 1e-6)
+            forcing = {}
+            for n in NL_OUT:
+                sc = max(float(np.abs(wt[n]).max()), 1e-30) if n != "covptot" else 1.0
+                forcing[n] = rng.normal(0.0, 1.0, size=wt[n].shape) * sc
+                forcing[n][nlev_of(n, nz):] = 0.0
+            wa, wai = run_oracle_ad(fields, forcing, eta, tdt, ext)
+            ga, gai = run_hip_ad(fields, forcing, eta, tdt, ext, gpu, nx, nz)
+            for n in NL_OUT:
+                k = nlev_of(n, nz)
+                partner = {"fplsl": "fplsn", "fplsn": "fplsl", "fhpsl": "fhpsn", "fhpsn": "fhpsl"}.get(n, n)
+                sc = max(float(np.abs(wa[n]).max()), float(np.abs(wa[partner]).max()), floor[n])
+                assert_close(f"AD {n} {tag}", ga[n][:k], wa[n][:k], dtype, scale=sc)
             for n in NL_IN:
                 k = nz + 1 if n in ("aph", "lu") else nz
-                assert_close(f"AD {n}_i {tag}", gai[n][:k], wai[n][:k], dtype, rtol_mul=1000.0)
+                by_column(f"AD {n}_i {tag}", gai[n][:k], wai[n][:k], 1e-3 if (evap and n == "lu") else 1e-5)
         done += 1
         if it % 10 == 9:
             print(f"{it + 1} cases ok (last: {tag})", flush=True)

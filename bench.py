@@ -7,17 +7,26 @@ launches through the C ABI of libcloudsc2_hip.so.  Inputs are synthetic columns 
 in HBM (gt4py_dwarf_p_cloudsc2_tl_ad_amd/synthetic.py; the reference's data/input.h5 is not
 available) and are resident before the timed region starts.
 
-  python bench.py --gpus 1 --steps 50 --warmup 5
+  python bench.py [--gpus N] [--steps K] [--warmup W]            # N > 1: starts its own N ranks (see below)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-         --master-port P bench.py --gpus N --steps K --warmup W
+         --master-port P bench.py --gpus N --steps K --warmup W  # same thing, ranks started by the caller
 
-N > 1: one process per GPU, every rank owns `--cols` columns of a global N*cols-column problem
-(weak scaling; columns are independent, so there is NO data-path collective).  RCCL is used only
-for the barrier / max-over-ranks timing and for the final validation-norm all-reduce.
+Modes
+  default      weak scaling: every rank owns `--cols` (65 536) fp64 columns of a global N*cols-column problem.
+  --config 5   BASELINE.json configs[4]: ONE global problem of 4 194 304 fp32 columns split N ways
+               (`cols = 4 194 304 / N`, "scaling": "strong", "dtype": "f32").
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (`nl_ring_kernel`, the LDS-ring load path of cloudsc2_nl): algorithmic bytes
-per launch (28 536 B/column fp64) / the kernel's mean duration measured with HIP
-events on the launch stream.  `cpu_baseline` times the C/OpenMP and NumPy restatements on a bounded sample.
+N > 1: one process per GPU.  Columns are independent, so there is NO data-path collective; RCCL is used only for
+the barrier, the max-over-ranks time and the final validation-norm all-reduce.  When `--gpus N > 1` is given to a
+plain `python bench.py` (no WORLD_SIZE in the environment), this process starts `python -m torch.distributed.run`
+with N ranks as a CHILD process - before torch is imported or any GPU call is made here - relays rank 0's JSON
+line and exits with the child's return code.
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel of the step (the `cloudsc2_nl` kernel; its name
+is the one the launcher reports): algorithmic bytes per launch (3 567 words per column) / the kernel's
+mean duration measured with HIP events on the launch stream.  At N = 1 the line also carries `roofline_tl`,
+`roofline_ad` (65 536 fp64 columns), `roofline_nl_f32` (524 288 fp32 columns = the per-GPU shard of config 5 on 8
+GPUs) and `cpu_baseline` (the C/OpenMP and NumPy restatements on a bounded sample).
 """
 from __future__ import annotations
 
@@ -31,24 +40,84 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 NL_WORDS_PER_COL = 3567          # 15*137 + 138 read, 6*137 + 4*138 written
+TLAD_WORDS_PER_COL = 7134        # rows a3 / a5: twice the NL count (state + perturbation / adjoint fields)
 SAT_WORDS_PER_COL = 411          # 2 in, 1 out over 137 levels
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
+CONFIG5_COLUMNS = 4194304        # BASELINE.json configs[4]
+METRIC = "columns/sec at 137 levels fp64; achieved HBM GB/s vs MI355X roofline"
+METRIC_C5 = ("columns/sec at 137 levels fp32, 4 194 304 columns sharded over the GPUs (BASELINE configs[4]); "
+             "achieved HBM GB/s vs MI355X roofline")
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--cols", type=int, default=65536, help="columns per GPU")
+    ap.add_argument("--config", type=int, choices=[2, 5], default=2,
+                    help="2 (default): BASELINE configs[1], 65 536 fp64 columns per GPU, weak scaling; "
+                         "5: BASELINE configs[4], 4 194 304 fp32 columns split over --gpus, strong scaling")
+    ap.add_argument("--cols", type=int, default=None, help="columns per GPU (default 65536; --config 5: 4194304 / gpus)")
     ap.add_argument("--nlev", type=int, default=137)
-    ap.add_argument("--precision", choices=["double", "single"], default="double")
+    ap.add_argument("--precision", choices=["double", "single"], default=None)
     ap.add_argument("--cpu-cols", type=int, default=16384,
                     help="columns of the CPU-baseline sample (0 disables the baseline)")
     ap.add_argument("--no-roofline-events", action="store_true")
-    return ap.parse_args()
+    ap.add_argument("--no-extra-rooflines", action="store_true",
+                    help="skip the TL / AD / fp32-NL kernel legs (N = 1 only)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="plumbing rehearsal without a GPU: gloo instead of RCCL, shard bookkeeping and the "
+                         "reductions only, NO kernels (value is null) - used by the CPU tests of the launcher")
+    args = ap.parse_args(argv)
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.config == 5:
+        if args.precision not in (None, "single"):
+            ap.error("--config 5 is the fp32 configuration")
+        args.precision = "single"
+        if args.cols is None:
+            if CONFIG5_COLUMNS % args.gpus:
+                ap.error(f"--config 5: {CONFIG5_COLUMNS} columns do not split over {args.gpus} GPUs")
+            args.cols = CONFIG5_COLUMNS // args.gpus
+    else:
+        args.precision = args.precision or "double"
+        args.cols = 65536 if args.cols is None else args.cols
+    return args
 
 
+# ------------------------------------------------------------------------------------------------ launcher
+def launch_ranks(args, argv) -> int:
+    """Plain `python bench.py --gpus N` (N > 1, no WORLD_SIZE): start the N ranks as a child torchrun job.
+    Nothing here touches torch or the GPU, so the parent never holds a HIP context; the child's stdout is scanned
+    for rank 0's JSON line (the only thing written to this process's stdout), everything else goes to stderr."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: the only mode this pool's driver supports
+    print(f"[bench] starting {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    seen = 0
+    for line in p.stdout:
+        if line.lstrip().startswith('{"metric"'):
+            seen += 1
+            if seen == 1:
+                print(line.rstrip("\n"), flush=True)
+                continue
+        sys.stderr.write(line)
+    rc = p.wait()
+    if rc == 0 and seen != 1:
+        print(f"[bench] expected ONE JSON line from rank 0, saw {seen}", file=sys.stderr)
+        return 1
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
 def cpu_baseline(cols: int, nz: int, np_dtype, budget_s: float = 8.0):
     """CPU baselines on the host, saturation + cloudsc2_nl on `cols` synthetic columns (BASELINE configs[0] size):
       * headline `value`: the plain-C + OpenMP restatement (oracle/cloudsc2_nl_omp.c, SURVEY 8d "restatement B")
@@ -98,8 +167,8 @@ def cpu_baseline(cols: int, nz: int, np_dtype, budget_s: float = 8.0):
 
         c_runs, c_el = loop(c_step, budget_s)
         res.update(value=cols * c_runs / c_el, cores=threads,
-                   sample=f"plain-C + OpenMP restatement (oracle/cloudsc2_nl_omp.c, {threads} threads, scalar libm), "
-                          f"{what} float64, {c_runs} runs in {c_el:.1f} s, synthetic-parameters")
+                   sample=f"plain-C + OpenMP restatement (oracle/cloudsc2_nl_omp.c, {threads} threads, scalar libm, "
+                          f"-O2), {what} float64, {c_runs} runs in {c_el:.1f} s, synthetic-parameters")
     except Exception as exc:  # the C library is optional test infrastructure: fall back to the NumPy figure
         res.update(value=numpy_rate, cores=1, sample=res["numpy_1core"]["sample"] + f" (C restatement unavailable: {exc})")
     return res
@@ -120,46 +189,159 @@ class _StdoutToStderr:
         os.close(self._saved)
 
 
-def pmc_traffic(nx: int, precision: str):
-    """HBM bytes per cloudsc2_nl launch from the rocprofv3 PMC passes committed under profiles/ (separate
-    FETCH_SIZE / WRITE_SIZE passes of this same command, profiles/run_rocprof.sh).  gfx950 correction
-    (MI355X_MICROARCH.md, HBM): FETCH_SIZE tallies the 128-B requests of a wide streaming read at 64 B ->
-    doubled; WRITE_SIZE is exact; both are in KiB.  None when no summary matches this workload."""
-    if nx != 65536 or precision != "double":
-        return None, None
-    path = os.path.join(ROOT, "profiles", "r01", "nl_fp64_65536_pmc.json")
-    try:
-        with open(path) as fh:
-            pm = json.load(fh)
-        k = ([v for n, v in pm.items() if "nl_ring_kernel" in n] or [v for n, v in pm.items() if "nl_kernel" in n])[0]
-        fetch = k["FETCH_SIZE"]["mean_per_dispatch"] * 1024.0
-        write = k["WRITE_SIZE"]["mean_per_dispatch"] * 1024.0
-    except (OSError, KeyError, IndexError, ValueError):
-        return None, None
-    return 2.0 * fetch + write, (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), {os.path.relpath(path, ROOT)}: "
-                                 f"2 x {fetch / 1e9:.3f} GB read + {write / 1e9:.3f} GB written per launch")
+# ------------------------------------------------------------------------------------------------ PMC traffic
+_PMC_FILES = (
+    # (columns, precision) -> summaries of the separate FETCH_SIZE / WRITE_SIZE passes, newest round first
+    ((65536, "double"), ("profiles/r02/nl_fp64_65536_pmc.json", "profiles/r02/all_kernels_fp64_65536_pmc.json",
+                         "profiles/r01/nl_fp64_65536_pmc.json", "profiles/r01/all_kernels_fp64_65536_pmc.json")),
+    ((524288, "single"), ("profiles/r02/all_kernels_fp32_524288_pmc.json",)),
+)
 
 
-def main():
-    args = parse_args()
+def pmc_traffic(kernel_substr: str, nx: int, precision: str):
+    """HBM bytes per launch of the kernel whose name contains `kernel_substr`, from the rocprofv3 PMC passes committed
+    under profiles/ (separate FETCH_SIZE / WRITE_SIZE passes, profiles/run_rocprof*.sh).  gfx950 correction
+    (MI355X_MICROARCH.md, HBM): FETCH_SIZE tallies the 128-B requests of a wide streaming read at 64 B -> doubled;
+    WRITE_SIZE is exact; both are in KiB.  (None, None) when no committed summary matches this workload."""
+    for key, files in _PMC_FILES:
+        if key != (nx, precision):
+            continue
+        for rel in files:
+            try:
+                with open(os.path.join(ROOT, rel)) as fh:
+                    pm = json.load(fh)
+                k = [v for n, v in pm.items() if kernel_substr in n][0]
+                fetch = k["FETCH_SIZE"]["mean_per_dispatch"] * 1024.0
+                write = k["WRITE_SIZE"]["mean_per_dispatch"] * 1024.0
+            except (OSError, KeyError, IndexError, ValueError):
+                continue
+            return 2.0 * fetch + write, (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), {rel}: "
+                                         f"2 x {fetch / 1e9:.3f} GB read + {write / 1e9:.3f} GB written per launch")
+    return None, None
+
+
+def roofline_entry(kernel: str, words_per_col: int, wsize: int, nx: int, precision: str, ms: float, **extra):
+    nbytes = words_per_col * wsize * nx
+    achieved = nbytes / (ms * 1e-3) / 1e9
+    traffic, src = pmc_traffic(kernel.split("::")[-1], nx, precision)
+    d = {"kernel": kernel, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch",
+         "traffic_source": src, "bytes_per_launch": nbytes, "avg_launch_ms": ms,
+         "kernel_columns_per_s": nx / (ms * 1e-3), "columns": nx, "dtype": "f64" if wsize == 8 else "f32"}
+    d.update(extra)
+    return d
+
+
+# ------------------------------------------------------------------------------------------------ state
+def make_resident_state(total, nz, col0, nx, np_dtype, device, chunk=262144):
+    """This rank's slice [col0, col0 + nx) of the global `total`-column synthetic problem, generated on the device
+    in column chunks (the generator works in float64 temporaries: bounded at ~0.3 GB each, whatever nx is)."""
+    import torch
+
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.synthetic import make_state
+
+    if nx <= chunk:
+        return make_state(total, nz, col0=col0, ncols=nx, dtype=np_dtype, device=device)
+    out = None
+    for c in range(0, nx, chunk):
+        n = min(chunk, nx - c)
+        part = make_state(total, nz, col0=col0 + c, ncols=n, dtype=np_dtype, device=device)
+        if out is None:
+            out = {k: torch.empty((nz + 1, nx), dtype=v.dtype, device=device) for k, v in part.items()}
+        for k, v in part.items():
+            out[k][:, c:c + n] = v
+        del part
+    return out
+
+
+def dry_run(args, rank, world):
+    """Launcher / rendezvous / shard bookkeeping rehearsal on the CPU (gloo): no kernels, no GPU."""
     import numpy as np
     import torch
+    import torch.distributed as dist
+
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.synthetic import eta_levels, make_state
+
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:
+        dist.init_process_group("gloo")
+    nx, nz = args.cols, args.nlev
+    np_dtype = np.float64 if args.precision == "double" else np.float32
+    n = min(nx, 64)      # a few columns of this rank's slice: enough to show the shards differ and tile the global problem
+    s = make_state(nx * world, nz, col0=rank * nx, ncols=n, dtype=np_dtype)
+    eta = eta_levels(nz, dtype=np_dtype)
+    t = torch.tensor([float(np.abs(s["f_t"]).sum()), float(rank * nx), float(eta.sum())], dtype=torch.float64)
+    first = t.clone()
+    if dist.is_initialized():
+        dist.barrier()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        tm = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        res = base_record(args, world, nx, nz, value=None, ms_per_step=None,
+                          ranks=dist.get_world_size() if dist.is_initialized() else None, backend="gloo (dry run)")
+        res.update(dry_run=True, data="dry run: no kernels were launched",
+                   shard_check={"col0_sum": float(t[1]), "eta_sum_x_world": float(t[2]), "eta_sum": float(first[2])})
+        print(json.dumps(res), flush=True)
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def base_record(args, world, nx, nz, value, ms_per_step, ranks, backend):
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.params import DEFAULT_TIMESTEP_S
+
+    c5 = args.config == 5
+    total = nx * world
+    return {
+        "metric": METRIC_C5 if c5 else METRIC,
+        "value": value,
+        "unit": "columns/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "strong" if c5 else "weak",
+        "vs_baseline": None,
+        "dtype": "f64" if args.precision == "double" else "f32",
+        "data": "synthetic columns + synthetic-parameters (reference data/input.h5 unavailable)",
+        "config": {
+            "workload": (f"BASELINE configs[4]: CLOUDSC2-NL (saturation + cloudsc2_nl) fp32, {total} cols x {nz} lev "
+                         f"sharded across {world} GPU(s), {nx} columns per GPU" if c5 else
+                         f"BASELINE configs[1]: CLOUDSC2-NL (saturation + cloudsc2_nl), {nx} cols x {nz} lev per GPU, "
+                         f"{args.precision}, {world} GPU(s), {total} columns total"),
+            "columns_per_gpu": nx, "columns_total": total, "levels": nz, "timestep_s": DEFAULT_TIMESTEP_S,
+            "parallelism": f"column-sharded x{world}, no data-path collective",
+        },
+        "rccl_ranks": ranks,
+        "collective_backend": backend,
+    }
+
+
+# ------------------------------------------------------------------------------------------------ main
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args, argv))       # nothing has touched torch / the GPU in this process
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    if args.dry_run:
+        return dry_run(args, rank, world)
+
+    import numpy as np
+    import torch
 
     import __graft_entry__ as ge
 
     ge.build()
-    from gt4py_dwarf_p_cloudsc2_tl_ad_amd import storage
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd import _lib, storage
     from gt4py_dwarf_p_cloudsc2_tl_ad_amd.params import DEFAULT_TIMESTEP_S, default_externals
-    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.stencils import NL_OUT, compile_stencil
-    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.synthetic import eta_levels, make_state
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.stencils import INC, NL_IN, NL_OUT, compile_stencil
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.synthetic import eta_levels
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
@@ -182,9 +364,11 @@ def main():
     total = nx * world
     ext = default_externals()
     dt = DEFAULT_TIMESTEP_S
+    com = dict(origin=(0, 0, 0), validate_args=False, exec_info=None)
+    last_kernel = lambda: _lib.last_kernel()  # noqa: E731
 
     # resident state: this rank's slice [rank*nx, (rank+1)*nx) of the global problem
-    s = make_state(total, nz, col0=rank * nx, ncols=nx, dtype=np_dtype, device=device)
+    s = make_resident_state(total, nz, rank * nx, nx, np_dtype, device)
     eta = torch.as_tensor(eta_levels(nz, dtype=np_dtype), device=device)  # from GLOBAL column 0
     f = {k: storage.logical_view(v) for k, v in s.items()}
     qsat = storage.zeros(nx, nz, np_dtype, device)
@@ -194,11 +378,15 @@ def main():
     sat = compile_stencil("saturation", ext)
     nl = compile_stencil("cloudsc2_nl", ext)
 
+    def sat_only():
+        sat(in_ap=f["f_ap"], in_t=f["f_t"], out_qsat=qsat, domain=(nx, 1, nz), **com)
+
+    def nl_only():
+        nl(**ins, **outs, in_eta=eta, dt=dt, domain=(nx, 1, nz + 1), **com)
+
     def step():
-        sat(in_ap=f["f_ap"], in_t=f["f_t"], out_qsat=qsat, origin=(0, 0, 0), domain=(nx, 1, nz),
-            validate_args=False, exec_info=None)
-        nl(**ins, **outs, in_eta=eta, dt=dt, origin=(0, 0, 0), domain=(nx, 1, nz + 1),
-           validate_args=False, exec_info=None)
+        sat_only()
+        nl_only()
 
     def barrier():
         torch.cuda.synchronize()
@@ -206,34 +394,34 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # dominant-kernel duration: HIP events on the launch stream (torch's current stream, the one the C ABI
-    # launches on) around EVERY cloudsc2_nl launch of a second pass over the timed region's pattern
-    # (saturation, cloudsc2_nl, ...).  All launches and event records are enqueued before the first
-    # synchronisation, so the GPU never waits for the host and an event interval is kernel time only;
-    # rocprofv3 --kernel-trace of this command reports the same average (profiles/).
-    nl_ms = None
-    nl_train_ms = None
-    copy_gbs = None
-    if not args.no_roofline_events:
-        def nl_only():
-            nl(**ins, **outs, in_eta=eta, dt=dt, origin=(0, 0, 0), domain=(nx, 1, nz + 1),
-               validate_args=False, exec_info=None)
-
-        for _ in range(20):          # untimed: bring the GPU out of its idle power state first
-            step()
-        reps = max(10, min(args.steps, 50))
+    def event_times(fn, reps, before=None):
+        """mean HIP-event interval around each `fn()` of a train of `reps` (+2 discarded) launches; everything is
+        enqueued before the first synchronisation, so the GPU never waits for the host"""
         evs = []
-        for _ in range(reps):
-            sat(in_ap=f["f_ap"], in_t=f["f_t"], out_qsat=qsat, origin=(0, 0, 0), domain=(nx, 1, nz),
-                validate_args=False, exec_info=None)
+        for _ in range(reps + 2):
+            if before is not None:
+                before()
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            nl_only()
+            fn()
             b.record()
             evs.append((a, b))
         torch.cuda.synchronize()
         times = [a.elapsed_time(b) for a, b in evs][2:]
-        nl_ms = sum(times) / len(times)
+        return sum(times) / len(times)
+
+    # dominant-kernel duration: HIP events on the launch stream (torch's current stream, the one the C ABI
+    # launches on) around EVERY cloudsc2_nl launch of a pass over the timed region's pattern
+    # (saturation, cloudsc2_nl, ...); rocprofv3 --kernel-trace of this command reports the same average (profiles/).
+    nl_ms = nl_train_ms = copy_gbs = None
+    nl_kernel_name = None
+    extra = {}
+    if not args.no_roofline_events:
+        for _ in range(20):          # untimed: bring the GPU out of its idle power state first
+            step()
+        nl_kernel_name = last_kernel()
+        reps = max(10, min(args.steps, 50))
+        nl_ms = event_times(nl_only, reps, before=sat_only)
         # the same kernel in a back-to-back train (no other kernel in between), for reference
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
@@ -256,16 +444,65 @@ def main():
         copy_gbs = 2 * src.numel() * 8 * 5 / (a.elapsed_time(b) * 1e-3) / 1e9
         del src, dst
 
+        # ---- the other kernels of the path, each against its own roofline (N = 1, headline configuration only)
+        if world == 1 and not args.no_extra_rooflines and args.config == 2 and nx <= 131072:
+            Z = lambda: storage.zeros(nx, nz, np_dtype, device)  # noqa: E731
+            extn = dict(ext, NLEV=nz)
+            inc_out = {"out_" + n + "_i": Z() for n in INC}
+            compile_stencil("state_increment", {"IGNORE_SUPSAT": True})(
+                **{"in_" + n: ins["in_" + n] for n in INC}, **inc_out, f=0.01, domain=(nx, 1, nz + 1), **com)
+            fi = {"in_" + n + "_i": inc_out["out_" + n + "_i"] for n in NL_IN}
+            tl_out = {"out_" + n: Z() for n in NL_OUT}
+            tl_out.update({"out_" + n + "_i": Z() for n in NL_OUT})
+            tl = compile_stencil("cloudsc2_tl", extn)
+            tl_call = lambda: tl(**ins, **fi, **tl_out, in_eta=eta, dt=dt, domain=(nx, 1, nz + 1), **com)  # noqa: E731
+            for _ in range(3):
+                tl_call()
+            tl_name = last_kernel()
+            tl_ms = event_times(tl_call, 20)
+            extra["roofline_tl"] = roofline_entry(tl_name, TLAD_WORDS_PER_COL, wsize, nx, args.precision, tl_ms)
+            ad_in = {"in_" + n + "_i": tl_out["out_" + n + "_i"] for n in NL_OUT}
+            ad_out = {"out_" + n: tl_out["out_" + n] for n in NL_OUT}
+            ad_out.update({"out_" + n + "_i": Z() for n in NL_IN})
+            ad = compile_stencil("cloudsc2_ad", extn)
+            ad_call = lambda: ad(**ins, **ad_in, **ad_out, in_eta=eta, dt=dt, domain=(nx, 1, nz + 1), **com)  # noqa: E731
+            for _ in range(3):
+                ad_call()
+            ad_name = last_kernel()
+            ad_ms = event_times(ad_call, 20)
+            extra["roofline_ad"] = roofline_entry(ad_name, TLAD_WORDS_PER_COL, wsize, nx, args.precision, ad_ms)
+            del inc_out, fi, tl_out, ad_in, ad_out
+            # cloudsc2_nl fp32 at the per-GPU shard of BASELINE configs[4] on 8 GPUs (524 288 columns)
+            n32 = CONFIG5_COLUMNS // 8
+            s32 = make_resident_state(n32, nz, 0, n32, np.float32, device)
+            eta32 = torch.as_tensor(eta_levels(nz, dtype=np.float32), device=device)
+            in32 = {"in_" + k[2:]: storage.logical_view(v) for k, v in s32.items()}
+            in32["in_qsat"] = storage.zeros(n32, nz, np.float32, device)
+            out32 = {"out_" + n: storage.zeros(n32, nz, np.float32, device) for n in NL_OUT}
+            sat32 = lambda: sat(in_ap=in32["in_ap"], in_t=in32["in_t"], out_qsat=in32["in_qsat"],  # noqa: E731
+                                domain=(n32, 1, nz), **com)
+            nl32 = lambda: nl(**in32, **out32, in_eta=eta32, dt=dt, domain=(n32, 1, nz + 1), **com)  # noqa: E731
+            for _ in range(3):
+                sat32()
+                nl32()
+            name32 = last_kernel()
+            ms32 = event_times(nl32, 10, before=sat32)
+            extra["roofline_nl_f32"] = roofline_entry(name32, NL_WORDS_PER_COL, 4, n32, "single", ms32,
+                                                      what="per-GPU shard of BASELINE configs[4] on 8 GPUs, timed "
+                                                           "inside the (saturation, cloudsc2_nl) pattern")
+            del s32, in32, out32
+            torch.cuda.empty_cache()
+
     # ---- the timed region: W warm-up steps, then EXACTLY K steps between barrier + synchronize pairs.  It runs AFTER the
-    # event-timed passes above on purpose: those ~150 launches bring the GPU out of its idle power state, so that the
-    # wall-clock figure is not dominated by the clock ramp of the first milliseconds (with 5 warm-up steps straight
-    # from idle the same 50 steps measured 377 us per step instead of 343 us, profiles/host_overhead.py).
+    # event-timed passes above on purpose: those launches bring the GPU out of its idle power state.  Garbage collection
+    # happens BEFORE the warm-up and the collector stays off until the window closes, so the warm-up runs straight into
+    # the opening barrier and the GPU idles only for that synchronisation (every stencil call builds small ctypes arrays).
     import gc
 
+    gc.collect()
+    gc.disable()
     for _ in range(args.warmup):
         step()
-    gc.collect()
-    gc.disable()        # no collector pause inside the wall-clock window (every stencil call builds small ctypes arrays)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -289,8 +526,7 @@ def main():
         ins2 = {k: v for k, v in ins.items() if k != "in_qsat"}
 
         def fused_step():
-            nls(**ins2, out_qsat=qsat2, **outs2, in_eta=eta, dt=dt, origin=(0, 0, 0), domain=(nx, 1, nz + 1),
-                validate_args=False, exec_info=None)
+            nls(**ins2, out_qsat=qsat2, **outs2, in_eta=eta, dt=dt, domain=(nx, 1, nz + 1), **com)
 
         for _ in range(args.warmup):
             fused_step()
@@ -302,7 +538,8 @@ def main():
         fel = time.perf_counter() - t1
         same = all(bool(torch.equal(outs2[k], outs[k])) for k in outs) and bool(torch.equal(qsat2, qsat))
         fused = {"ms_per_step": 1e3 * fel / args.steps, "value": nx * args.steps / fel, "unit": "columns/s",
-                 "results_equal_unfused": same, "what": "saturation + cloudsc2_nl as one launch (cloudsc2_nl_fused_*)"}
+                 "kernel": last_kernel(), "results_equal_unfused": same,
+                 "what": "saturation + cloudsc2_nl as one launch (cloudsc2_nl_fused_*)"}
         del qsat2, outs2
 
     # validation norm (the only data reduction across ranks): sum of every NL output
@@ -313,47 +550,20 @@ def main():
     norm = [float(x) for x in norm.cpu()]
 
     if rank == 0:
-        ms_per_step = 1e3 * elapsed / args.steps
-        value = total * args.steps / elapsed
-        res = {
-            "metric": "columns/sec at 137 levels fp64; achieved HBM GB/s vs MI355X roofline",
-            "value": value,
-            "unit": "columns/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": ms_per_step,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f64" if args.precision == "double" else "f32",
-            "data": "synthetic columns + synthetic-parameters (reference data/input.h5 unavailable)",
-            "config": {
-                "workload": f"CLOUDSC2-NL (saturation + cloudsc2_nl), {nx} cols x {nz} lev per GPU, "
-                            f"{args.precision}, {world} GPU(s), {total} columns total",
-                "columns_per_gpu": nx, "levels": nz, "timestep_s": dt,
-                "parallelism": f"column-sharded x{world}, no data-path collective",
-            },
-            "outputs_finite": finite,
-            "validation_norm": dict(zip(NL_OUT, norm)),
-        }
+        res = base_record(args, world, nx, nz, value=total * args.steps / elapsed,
+                          ms_per_step=1e3 * elapsed / args.steps,
+                          ranks=dist.get_world_size() if dist is not None else None,
+                          backend="nccl (RCCL)" if dist is not None else "none (single process)")
+        res["outputs_finite"] = finite
+        res["validation_norm"] = dict(zip(NL_OUT, norm))
         if nl_ms is not None:
-            nl_bytes = NL_WORDS_PER_COL * wsize * nx
-            achieved = nl_bytes / (nl_ms * 1e-3) / 1e9
-            traffic, traffic_src = pmc_traffic(nx, args.precision)
-            res["roofline"] = {
-                "kernel": "cs2::nl_ring_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch",
-                "traffic_source": traffic_src,
-                "bytes_per_launch": nl_bytes, "avg_launch_ms": nl_ms,
-                "kernel_columns_per_s": nx / (nl_ms * 1e-3),
-                "avg_launch_ms_back_to_back": nl_train_ms,
-                "box_copy_ceiling_GBs": copy_gbs,
-            }
+            res["roofline"] = roofline_entry(nl_kernel_name, NL_WORDS_PER_COL, wsize, nx, args.precision, nl_ms,
+                                             avg_launch_ms_back_to_back=nl_train_ms, box_copy_ceiling_GBs=copy_gbs)
+        res.update(extra)
         if fused is not None:
             res["fused_step"] = fused
         if world == 1 and args.cpu_cols > 0:
-            res["cpu_baseline"] = cpu_baseline(args.cpu_cols, nz, np_dtype)
+            res["cpu_baseline"] = cpu_baseline(args.cpu_cols, nz, np.float64)
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -23,7 +23,8 @@ INC_NUM = 16
 
 #: every symbol include/cloudsc2_hip.h declares (tests check the library exports all of them)
 EXPORTED_SYMBOLS = (
-    "cloudsc2_abi_version", "cloudsc2_params_sizeof", "cloudsc2_last_error", "cloudsc2_device_count",
+    "cloudsc2_abi_version", "cloudsc2_params_sizeof", "cloudsc2_last_error", "cloudsc2_last_kernel",
+    "cloudsc2_device_count",
     "cloudsc2_nl_f64", "cloudsc2_nl_f32",
     "cloudsc2_nl_fused_f64", "cloudsc2_nl_fused_f32",
     "cloudsc2_nl_taylor_blocks", "cloudsc2_nl_taylor_f64", "cloudsc2_nl_taylor_f32",
@@ -49,6 +50,8 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.cloudsc2_params_sizeof.argtypes = []
     lib.cloudsc2_last_error.restype = c_char_p
     lib.cloudsc2_last_error.argtypes = []
+    lib.cloudsc2_last_kernel.restype = c_char_p
+    lib.cloudsc2_last_kernel.argtypes = []
     lib.cloudsc2_device_count.restype = c_int32
     lib.cloudsc2_device_count.argtypes = []
     lib.cloudsc2_nl_taylor_blocks.restype = c_int32
@@ -119,6 +122,11 @@ def load() -> ctypes.CDLL:
 
 def last_error() -> str:
     return load().cloudsc2_last_error().decode("utf-8", "replace")
+
+
+def last_kernel() -> str:
+    """Name of the kernel the last stencil call of this thread launched (diagnostics, e.g. for bench.py's record)."""
+    return load().cloudsc2_last_kernel().decode("utf-8", "replace")
 
 
 def check(rc: int, what: str) -> None:

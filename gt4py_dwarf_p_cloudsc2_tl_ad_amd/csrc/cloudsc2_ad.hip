@@ -968,6 +968,7 @@ int launch_ad(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
     else CS2_AD_LAUNCH_E(false, true);
 #undef CS2_AD_LAUNCH_E
 #undef CS2_AD_LAUNCH
+    note_kernel("cs2::ad_kernel");
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -81,6 +81,7 @@ int launch_saturation(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const
             hipLaunchKernelGGL((saturation_vec_kernel<T, 1>), vgrid, vblock, 0, stream, e, xk, nxv, nz, ls, ap, t, qsat, keep);
         else
             hipLaunchKernelGGL((saturation_vec_kernel<T, 2>), vgrid, vblock, 0, stream, e, xk, nxv, nz, ls, ap, t, qsat, keep);
+        note_kernel("cs2::saturation_vec_kernel");
         return hipGetLastError() == hipSuccess ? 0 : -1;
     }
     const dim3 grid((nx + kAuxBlock - 1) / kAuxBlock, nz), block(kAuxBlock);
@@ -90,6 +91,7 @@ int launch_saturation(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const
         hipLaunchKernelGGL((saturation_kernel<T, 1>), grid, block, 0, stream, e, xk, nx, ls, ap, t, qsat, keep);
     else
         hipLaunchKernelGGL((saturation_kernel<T, 2>), grid, block, 0, stream, e, xk, nx, ls, ap, t, qsat, keep);
+    note_kernel("cs2::saturation_kernel");
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -119,6 +121,7 @@ int launch_increment(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const 
     const dim3 grid((nx + kAuxBlock - 1) / kAuxBlock, nz + 1), block(kAuxBlock);
     hipLaunchKernelGGL((increment_kernel<T>), grid, block, 0, stream, nx, ls, ci, co, static_cast<T>(f),
                        int(p.IGNORE_SUPSAT));
+    note_kernel("cs2::increment_kernel");
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -143,6 +146,7 @@ int launch_perturb(int nx, int nz, int64_t ls, const T* const* in, const T* cons
     for (int i = 0; i < INC_NUM; ++i) { ci.p[i] = in[i]; cii.p[i] = in_i[i]; co.p[i] = out[i]; }
     const dim3 grid((nx + kAuxBlock - 1) / kAuxBlock, nz + 1), block(kAuxBlock);
     hipLaunchKernelGGL((perturb_kernel<T>), grid, block, 0, stream, nx, ls, ci, cii, co, static_cast<T>(f));
+    note_kernel("cs2::perturb_kernel");
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

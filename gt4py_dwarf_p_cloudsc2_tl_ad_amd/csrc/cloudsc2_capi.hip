@@ -27,6 +27,7 @@ int launch_perturb(int, int, int64_t, const T* const*, const T* const*, T* const
 namespace {
 
 thread_local char g_err[512] = "";
+thread_local const char* g_kernel = "";
 
 int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -36,7 +37,7 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
-constexpr int kMaxLevels = 4096;  // LDS table: 2 * (nz+1) * 8 B must stay well below 64 KiB
+constexpr int kMaxLevels = 4095;  // LDS table of the register-path kernels: 2 * (nz+1) * 8 B <= 64 KiB (no opt-in needed)
 
 int check_common(const char* fn, const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls) {
     if (!p) return fail(CLOUDSC2_E_ARG, "%s: params is NULL", fn);
@@ -184,11 +185,16 @@ int per_impl(const char* fn, const Cloudsc2Params* p, int32_t nx, int32_t nz, in
 
 }  // namespace
 
+namespace cs2 {
+void note_kernel(const char* name) { g_kernel = name; }
+}  // namespace cs2
+
 extern "C" {
 
 int32_t cloudsc2_abi_version(void) { return CLOUDSC2_ABI_VERSION; }
 int32_t cloudsc2_params_sizeof(void) { return (int32_t)sizeof(Cloudsc2Params); }
 const char* cloudsc2_last_error(void) { return g_err; }
+const char* cloudsc2_last_kernel(void) { return g_kernel; }
 int32_t cloudsc2_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) {

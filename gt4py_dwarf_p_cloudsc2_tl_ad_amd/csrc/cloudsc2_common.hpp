@@ -1,7 +1,8 @@
 // Shared device-side definitions for the CLOUDSC2 HIP kernels (gfx950 / CDNA4 only).
 //
 // Execution model used by every column kernel in this directory:
-//   * one lane = one atmospheric column, one wave64 = 64 adjacent columns, workgroup = 1 wave;
+//   * one lane = one atmospheric column, one wave64 = 64 adjacent columns, workgroup = 4 waves (kColBlock = 256
+//     threads: one wave per SIMD of a CU);
 //   * fields are [level][column], so every per-level access of a wave is one fully coalesced
 //     512-B (fp64) / 256-B (fp32) request;
 //   * the vertical loop is sequential per lane; the loop-carried precipitation state lives in
@@ -82,7 +83,14 @@ inline ExpK<T> make_expk() {
 }
 template <typename T> __device__ __forceinline__ T fexp(const ExpK<T>& k, T x);
 template <> __device__ __forceinline__ double fexp<double>(const ExpK<double>& k, double x) {
-    x = __builtin_fmin(__builtin_fmax(x, -746.0), 710.0);
+    {
+        // clamp; a NaN argument must stay NaN (v_max / v_min return their non-NaN operand, which would turn exp(NaN)
+        // into exp(-746) = 0 where the reference propagates the NaN): its high word is patched back in - 2 VALU
+        const double xc = __builtin_fmin(__builtin_fmax(x, -746.0), 710.0);
+        int hi = __double2hiint(xc);
+        if (x != x) hi = 0x7FF80000;
+        x = __hiloint2double(hi, __double2loint(xc));
+    }
     const double n = __builtin_rint(x * k.l2e);
     double r = __builtin_fma(-n, k.ln2h, x);
     r = __builtin_fma(-n, k.ln2l, r);
@@ -250,6 +258,9 @@ template <typename T, int N>
 struct CPtrs { const T* p[N]; };
 template <typename T, int N>
 struct MPtrs { T* p[N]; };
+
+// diagnostics: the launchers record the name of the kernel they enqueued (cloudsc2_last_kernel(), thread-local)
+void note_kernel(const char* name);
 
 // Per-level LDS table: eta[k] and scalm[k] = ZSCAL * max(eta[k]-0.2, ZEPS1)^0.2
 // (nonlinear/_stencils/cloudsc2.py:127).  `pow` is evaluated once per level per workgroup instead

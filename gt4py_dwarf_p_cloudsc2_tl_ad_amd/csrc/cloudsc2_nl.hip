@@ -904,6 +904,7 @@ int launch_nl(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
         }
 #undef CS2_NL_RING_FLAGS
 #undef CS2_NL_RING_LAUNCH
+        note_kernel("cs2::nl_ring_kernel");
         return hipGetLastError() == hipSuccess ? 0 : -1;
     }
 #endif
@@ -913,6 +914,7 @@ int launch_nl(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
     else CS2_NL_FLAGS(3);
 #undef CS2_NL_FLAGS
 #undef CS2_NL_LAUNCH
+    note_kernel("cs2::nl_kernel");
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -615,6 +615,7 @@ int launch_tl(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
         if (evap) CS2_TL_LAUNCH(false, true); else CS2_TL_LAUNCH(false, false);
     }
 #undef CS2_TL_LAUNCH
+    note_kernel("cs2::tl_kernel");
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

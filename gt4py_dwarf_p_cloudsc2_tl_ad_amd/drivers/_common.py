@@ -92,14 +92,22 @@ def setup(args) -> Dict[str, Any]:
         nz = int(np.asarray(op.f["KLEV"]).reshape(-1)[0])
         nx = cfg.num_cols or int(np.asarray(op.f["KLON"]).reshape(-1)[0])
         grid = ComputationalGrid(GridConfig(nx=nx, ny=1, nz=nz))
-        gop = HDF5GridOperator(cfg.input_file, grid, gt4py_config=gcfg)
-        state: Dict[str, Any] = {}
-        for name, (h5, idx, half) in _STATE_H5.items():
-            kdim = K - 1 / 2 if half else K
-            from ..framework.grid import D5, IJ, ExpandedDim
-            dims_map = (IJ, ExpandedDim, kdim) if idx is None else (IJ, ExpandedDim, K, D5[idx])
-            h5_dims = (kdim, IJ) if idx is None else (D5, K, IJ)
-            state[name] = gop.get_field((I, J, kdim), "float", "", h5, h5_dims, dims_map)
+        from ..framework.grid import D5, IJ, ExpandedDim
+
+        def read_state(g, names, col0):
+            gop = HDF5GridOperator(cfg.input_file, g, gt4py_config=gcfg, column_offset=col0)
+            out: Dict[str, Any] = {}
+            for name in names:
+                h5, idx, half = _STATE_H5[name]
+                kdim = K - 1 / 2 if half else K
+                dims_map = (IJ, ExpandedDim, kdim) if idx is None else (IJ, ExpandedDim, K, D5[idx])
+                h5_dims = (kdim, IJ) if idx is None else (D5, K, IJ)
+                out[name] = gop.get_field((I, J, kdim), "float", "", h5, h5_dims, dims_map)
+            return out
+
+        # this rank's slice [rank * nx, (rank + 1) * nx) of the tiled global problem
+        rank, world = _rank_world()
+        state = read_state(grid, _STATE_H5, rank * nx)
         dt = timedelta(seconds=float(np.asarray(op.f["PTSPHY"]).reshape(-1)[0]))
         names = {k: np.asarray(op.f[k]).reshape(-1)[0] for k in op.f.keys() if np.asarray(op.f[k]).size == 1}
         base = default_externals()
@@ -126,10 +134,15 @@ def setup(args) -> Dict[str, Any]:
         groups = _groups_from_defaults()
         source = "synthetic columns (seed 20240807) + synthetic-parameters"
     state["time"] = datetime(1970, 1, 1)
-    # eta from GLOBAL column 0: identical on every rank by construction of the synthetic state
-    if use_file or _rank_world()[1] == 1:
+    # eta from GLOBAL column 0 (common/diagnostics.py:42-45 reads column 0 of the whole domain)
+    if _rank_world()[1] == 1 or (use_file and _rank_world()[0] == 0):
         eta_levels = EtaLevels(grid, enable_checks=cfg.sympl_enable_checks, gt4py_config=gcfg)
         state.update(eta_levels(state))
+    elif use_file:
+        # a rank whose first column is not global column 0 reads that one column of the file for it
+        g1 = ComputationalGrid(GridConfig(nx=1, ny=1, nz=nz))
+        eta_levels = EtaLevels(g1, enable_checks=cfg.sympl_enable_checks, gt4py_config=gcfg)
+        state.update(eta_levels(read_state(g1, ("f_ap", "f_aph"), 0)))
     else:
         eta = torch.as_tensor(synthetic.eta_levels(nz, dtype=gcfg.dtypes.float), device=device)
         state["f_eta"] = DataArray(eta, (K,), "")

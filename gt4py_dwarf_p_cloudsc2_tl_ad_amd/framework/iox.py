@@ -10,8 +10,10 @@ Data sources, in this order:
      parameters) - `data/input.h5` is not shipped with the reference (.MISSING_LARGE_BLOBS:1).  A notice
      is printed once; every number produced from it is "synthetic-parameters".
 
-Column tiling (build's choice, the upstream rule is not visible): logical column j reads file column
-j mod KLON.  Fields are returned as `DataArray`s over [level][column] storages with nz+1 levels.
+Column tiling (build's choice, the upstream rule is not visible): GLOBAL column j reads file column
+j mod KLON; a rank that owns the global columns [c0, c0 + nx) passes `column_offset=c0`, so the shards of a
+multi-GPU run are slices of ONE tiled global problem, not copies of its first nx columns.  Fields are returned as
+`DataArray`s over [level][column] storages with nz+1 levels.
 """
 from __future__ import annotations
 
@@ -122,10 +124,11 @@ class HDF5Operator:
 
 
 class HDF5GridOperator:
-    def __init__(self, filename: str, computational_grid, *, gt4py_config) -> None:
+    def __init__(self, filename: str, computational_grid, *, gt4py_config, column_offset: int = 0) -> None:
         self.filename = filename
         self.computational_grid = computational_grid
         self.gt4py_config = gt4py_config
+        self.column_offset = int(column_offset)   # global index of this grid's column 0 (build extension, see above)
         self.f = _open(filename)
 
     def get_field(self, grid_dims: Sequence[Any], dtype_name: str, units: str, h5_name: str,
@@ -146,5 +149,5 @@ class HDF5GridOperator:
             raise ValueError(f"{h5_name}: {nlev} levels in the file, {want} expected for dims {tuple(grid_dims)}")
         dt = getattr(self.gt4py_config.dtypes, dtype_name)
         kc = np.zeros((nz + 1, nx), dtype=dt)
-        kc[:nlev] = data[:, np.arange(nx) % klon]
+        kc[:nlev] = data[:, (self.column_offset + np.arange(nx)) % klon]
         return DataArray(storage.from_klayout(kc, dt, backend_device(self.gt4py_config)), tuple(grid_dims), units)

@@ -9,10 +9,11 @@ from .fields import DataArray, to_numpy
 
 
 def validate(fields: Mapping[str, Any], reference: Mapping[str, Any], *, atol: Optional[float] = None,
-             rtol: Optional[float] = None) -> bool:
+             rtol: Optional[float] = None, report: Optional[dict] = None) -> bool:
     """Prints one line per field present in both dicts (max abs / max rel error, pass/fail) and returns
     True iff all compared fields pass.  A reference name without a counterpart is reported, with the
-    `f_qv` -> `f_q` fix-up of SURVEY.md 4.2 (nonlinear/reference.py:32 vs microphysics.py:106)."""
+    `f_qv` -> `f_q` fix-up of SURVEY.md 4.2 (nonlinear/reference.py:32 vs microphysics.py:106).  `report`, when
+    given, receives the per-field figures (build extension for the tests; the reference prints only)."""
     atol = 0.0 if atol is None else atol
     rtol = 0.0 if rtol is None else rtol
     ok = True
@@ -34,4 +35,7 @@ def validate(fields: Mapping[str, Any], reference: Mapping[str, Any], *, atol: O
         print(f"  {name:12s}{'' if key == name else ' (as ' + key + ')'}: max abs err {err.max():.3e}, "
               f"max rel err {rel:.3e} -> {'OK' if good else 'MISMATCH'}")
         ok = ok and good
+        if report is not None:
+            report[name] = {"as": key, "max_abs_err": float(err.max()), "max_rel_err": rel, "ok": good,
+                            "shape": tuple(a.shape), "ref_shape": tuple(b.shape)}
     return ok

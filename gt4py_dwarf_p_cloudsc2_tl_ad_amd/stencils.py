@@ -37,6 +37,18 @@ _SFX = {torch.float64: "f64", torch.float32: "f32"}
 _IGNORED_PREFIX = "tmp_"
 
 
+def _windows_overlap(pa: int, pb: int, itemsize: int, nx: int, nlev: int, ls: int) -> bool:
+    """Do two [level][column] windows (nx columns, nlev levels, level stride ls elements) that start at byte
+    addresses pa / pb share an element?  Exact for windows of one allocation (column windows with lev_stride > nx
+    interleave without touching); a misaligned pair is judged by its byte ranges."""
+    d = pb - pa
+    if d % itemsize:
+        span = ((nlev - 1) * ls + nx) * itemsize
+        return pa < pb + span and pb < pa + span
+    q, r = divmod(d // itemsize, ls)            # d = q * ls + r, 0 <= r < ls
+    return (r < nx and abs(q) < nlev) or (ls - r < nx and abs(q + 1) < nlev)
+
+
 def _current_stream_ptr(device: torch.device) -> int:
     return int(torch.cuda.current_stream(device).cuda_stream)
 
@@ -86,7 +98,26 @@ class HipStencil:
                 if g != (nx, nlev, ls):
                     raise ValueError(f"{self.name}: argument {n} has (nx, nlev, lev_stride) = {g}, "
                                      f"expected {(nx, nlev, ls)}")
+            self._check_disjoint(fields, nx, nlev, ls, first.element_size())
         return nx, nz, ls, first.dtype, first.device
+
+    def _check_disjoint(self, fields: Mapping[str, torch.Tensor], nx: int, nlev: int, ls: int, itemsize: int) -> None:
+        """Debug check (validate_args=True): an output of a call must not share storage with any other field of the
+        same call.  The kernels stream level by level and cloudsc2_ad re-reads its inputs in the backward sweep, so an
+        in-place call would silently compute from overwritten data (SURVEY.md 5 "race detection"; the reference's
+        drivers never alias inputs and outputs of one call, adjoint/validation.py:149-150 rebinds TL outputs as AD
+        *inputs* only)."""
+        if nx == 0:
+            return
+        ptrs = {n: f.data_ptr() for n, f in fields.items()}
+        outs = [n for n in fields if n.startswith("out_")]
+        for o in outs:
+            for n, p in ptrs.items():
+                if n == o or (n in outs and n < o):      # every unordered pair once
+                    continue
+                if _windows_overlap(ptrs[o], p, itemsize, nx, nlev, ls):
+                    raise ValueError(f"{self.name}: output '{o}' overlaps '{n}' in memory - inputs and outputs of "
+                                     "one call must be disjoint storages")
 
     def _collect(self, kwargs: Dict[str, Any]) -> Dict[str, torch.Tensor]:
         fields = {}
@@ -112,6 +143,7 @@ class HipStencil:
         domain = kwargs.pop("domain", None)
         validate = bool(kwargs.pop("validate_args", True))
         exec_info: Optional[dict] = kwargs.pop("exec_info", None)
+        self._validate = validate
         scalar = 0.0
         if self.scalar_name:
             if self.scalar_name not in kwargs:
@@ -139,6 +171,15 @@ class HipStencil:
 
     def _launch(self, fields, eta, scalar, nx, nz, ls, sfx, stream) -> int:
         raise NotImplementedError
+
+    def _set_nlev(self, nz: int) -> None:
+        """`NLEV` is an external of the TL / AD stencils (tangent_linear/microphysics.py:85: the grid's nz).  When the
+        caller supplied one it must agree with the storages (checked with validate_args=True; otherwise the storages
+        win, as they must for the kernels' bounds); when it did not, it is derived from them."""
+        given = self.externals.get("NLEV")
+        if given is not None and int(given) != nz and getattr(self, "_validate", True):
+            raise ValueError(f"{self.name}: external NLEV={int(given)} does not match the storages (nz={nz})")
+        self.params.NLEV = nz
 
     def _fn(self, base: str, sfx: str) -> Callable:
         return getattr(self._lib, f"cloudsc2_{base}_{sfx}")
@@ -260,7 +301,7 @@ class Cloudsc2TLStencil(HipStencil):
     def _launch(self, fields, eta, scalar, nx, nz, ls, sfx, stream):
         if eta is None:
             raise TypeError("cloudsc2_tl: missing field argument 'in_eta'")
-        self.params.NLEV = nz
+        self._set_nlev(nz)
         return self._fn("tl", sfx)(
             ctypes.byref(self.params), nx, nz, ls,
             _ptrs(fields, ["in_" + n for n in NL_IN]), _ptrs(fields, ["in_" + n + "_i" for n in NL_IN]),
@@ -281,7 +322,7 @@ class Cloudsc2ADStencil(HipStencil):
     def _launch(self, fields, eta, scalar, nx, nz, ls, sfx, stream):
         if eta is None:
             raise TypeError("cloudsc2_ad: missing field argument 'in_eta'")
-        self.params.NLEV = nz
+        self._set_nlev(nz)
         return self._fn("ad", sfx)(
             ctypes.byref(self.params), nx, nz, ls,
             _ptrs(fields, ["in_" + n for n in NL_IN]), _ptrs(fields, ["in_" + n + "_i" for n in NL_OUT]),

@@ -22,7 +22,14 @@
  *   - the boolean externals LPHYLIN / LDRAIN1D / LEVAPLS2 / LREGCL / IGNORE_SUPSAT select a kernel
  *     instantiation, the numeric externals travel by value in `Cloudsc2Params`;
  *   - return value: 0 on success, <0 on error (CLOUDSC2_E_*); `cloudsc2_last_error()` returns a
- *     thread-local message.  Kernels are launched asynchronously on `stream`.
+ *     thread-local message.  Kernels are launched asynchronously on `stream`;
+ *   - threading: the library is written for ONE host thread per process and device (the one-process-per-GPU
+ *     model of the drivers).  Error text and kernel-name diagnostics are thread-local, but the launchers cache
+ *     per-device facts (CU count, the >64 KiB LDS opt-in of the ring kernels) in unsynchronised statics: calling
+ *     entry points of the same device concurrently from several threads needs external serialisation;
+ *   - inputs and outputs of one call must not overlap (no in-place calls): the kernels stream level by level
+ *     and cloudsc2_ad re-reads its inputs in its second sweep.  The Python stencil objects check this when
+ *     called with validate_args=True.
  */
 #ifndef CLOUDSC2_HIP_H
 #define CLOUDSC2_HIP_H
@@ -33,7 +40,7 @@
 extern "C" {
 #endif
 
-#define CLOUDSC2_ABI_VERSION 1
+#define CLOUDSC2_ABI_VERSION 2
 
 #define CLOUDSC2_OK 0
 #define CLOUDSC2_E_ARG (-1)      /* bad argument (null pointer, nx/nz/stride out of range)      */
@@ -64,6 +71,9 @@ typedef struct Cloudsc2Params {
 int32_t cloudsc2_abi_version(void);
 int32_t cloudsc2_params_sizeof(void);
 const char* cloudsc2_last_error(void);
+/* diagnostics: name of the kernel the calling thread's last successful entry-point call enqueued, e.g.
+ * "cs2::nl_ring_kernel" (LDS-ring load path) or "cs2::nl_kernel" (register prefetch); "" before the first launch */
+const char* cloudsc2_last_kernel(void);
 /* number of HIP devices visible to the library's runtime (0 if none / runtime unusable) */
 int32_t cloudsc2_device_count(void);
 

@@ -94,6 +94,7 @@ def saturation(in_ap, in_t, out_qsat, externals) -> None:
     """saturation.py:23-42 on domain (nx, 1, nz): levels 0 .. nz-1 of the (nz+1)-level arrays."""
     e = externals
     nz = in_ap.shape[0] - 1
+    _WORK["dtype"] = in_ap.dtype
     with np.errstate(**_ERR):
         t = in_t[:nz]
         ap = in_ap[:nz]
@@ -148,10 +149,10 @@ def f_cuadjtqs_nl(ap, t, q, e):
     """nonlinear/_stencils/cuadjtqs.py:40-68 (ICALL == 0 only, as the reference)."""
     assert e["ICALL"] == 0
     warm = t > e["RTT"]
-    z3es = np.where(warm, e["R3LES"], e["R3IES"])
-    z4es = np.where(warm, e["R4LES"], e["R4IES"])
-    z5alcp = np.where(warm, e["R5ALVCP"], e["R5ALSCP"])
-    zaldcp = np.where(warm, e["RALVDCP"], e["RALSDCP"])
+    z3es = _where(warm, e["R3LES"], e["R3IES"])
+    z4es = _where(warm, e["R4LES"], e["R4IES"])
+    z5alcp = _where(warm, e["R5ALVCP"], e["R5ALSCP"])
+    zaldcp = _where(warm, e["RALVDCP"], e["RALSDCP"])
     t, q = _cuadjtqs_nl_0(ap, t, q, z3es, z4es, z5alcp, zaldcp, e)
     t, q = _cuadjtqs_nl_0(ap, t, q, z3es, z4es, z5alcp, zaldcp, e)
     return t, q
@@ -166,7 +167,7 @@ def _trpaus(eta, t, nz, dtype):
     trpaus = np.full(nx, 0.1, dtype=dtype)
     for k in range(nz - 1):
         if eta[k] > 0.1 and eta[k] < 0.4:
-            trpaus = np.where(t[k] > t[k + 1], eta[k], trpaus)
+            trpaus = _where(t[k] > t[k + 1], eta[k], trpaus)
     return trpaus
 
 
@@ -180,13 +181,13 @@ def _crh2(eta_k, trpaus):
     bound1 = trpaus + deta2
     deta1 = 0.09 + 0.16 * (0.4 - trpaus) / 0.3
     bound2 = 1.0 - deta1
-    crh2 = np.where(
+    crh2 = _where(
         eta_k < trpaus,
         rh3,
-        np.where(
+        _where(
             eta_k < bound1,
             rh3 + (rh2 - rh3) * (eta_k - trpaus) / deta2,
-            np.where(eta_k < bound2, rh2, rh1 + (rh2 - rh1) * np.sqrt((1.0 - eta_k) / deta1)),
+            _where(eta_k < bound2, rh2, rh1 + (rh2 - rh1) * np.sqrt((1.0 - eta_k) / deta1)),
         ),
     )
     return crh2
@@ -199,15 +200,38 @@ NL_OUTPUTS = ("out_clc", "out_covptot", "out_fhpsl", "out_fhpsn", "out_fplsl", "
               "out_tnd_q", "out_tnd_qi", "out_tnd_ql", "out_tnd_t")
 
 
-def cloudsc2_nl(fields: Dict[str, np.ndarray], in_eta: np.ndarray, dt, externals) -> None:
+def _where(cond, a, b):
+    """np.where in the working precision.  With two scalar branches (externals are Python floats) NumPy returns a
+    float64 array, which would silently promote everything downstream of it in a float32 run; every field-valued
+    quantity of the stencils is held in the field precision instead (fp32 semantics: tests/golden/gtscript_exec.py,
+    make_reference_exec.py).  In a float64 run this is np.where."""
+    r = np.where(cond, a, b)
+    if r.dtype == np.float64 and _WORK["dtype"] == np.float32:
+        return r.astype(np.float32)
+    return r
+
+
+_WORK = {"dtype": np.dtype(np.float64)}   # set by each stencil entry point from its fields
+
+
+def _count(bc, name, mask) -> None:
+    if bc is not None:
+        bc[name] = bc.get(name, 0) + int(np.count_nonzero(mask))
+
+
+def cloudsc2_nl(fields: Dict[str, np.ndarray], in_eta: np.ndarray, dt, externals, branch_counts=None) -> None:
     """nonlinear/_stencils/cloudsc2.py:93-399.  `fields` holds the 16 `in_*` and 10 `out_*`
     arrays (nz+1, nx); outputs are written in place.  `out_fplsl[0]`/`out_fplsn[0]` are NOT
-    written, exactly as the reference."""
+    written, exactly as the reference.
+    `branch_counts` (a dict, optional): receives the number of grid points that took each branch of the scheme -
+    the coverage evidence of tests/test_branch_coverage.py; it does not change any result."""
     e = externals
+    bc = branch_counts
     F = fields
     in_ap, in_aph, in_lu, in_lude = F["in_ap"], F["in_aph"], F["in_lu"], F["in_lude"]
     in_mfd, in_mfu, in_qsat = F["in_mfd"], F["in_mfu"], F["in_qsat"]
     dtype = in_ap.dtype
+    _WORK["dtype"] = dtype
     nz = in_ap.shape[0] - 1
     nx = in_ap.shape[1]
     dt = dtype.type(dt)
@@ -255,9 +279,9 @@ def cloudsc2_nl(fields: Dict[str, np.ndarray], in_eta: np.ndarray, dt, externals
             # :141-160
             if e["LPHYLIN"] or e["LDRAIN1D"]:
                 cold = t < RTT
-                fwat = np.where(cold, 0.545 * (np.tanh(0.17 * (t - e["RLPTRC"])) + 1.0), 1.0)
-                z3es = np.where(cold, e["R3IES"], e["R3LES"])
-                z4es = np.where(cold, e["R4IES"], e["R4LES"])
+                fwat = _where(cold, 0.545 * (np.tanh(0.17 * (t - e["RLPTRC"])) + 1.0), 1.0)
+                z3es = _where(cold, e["R3IES"], e["R3LES"])
+                z4es = _where(cold, e["R4IES"], e["R4LES"])
                 foeew = e["R2ES"] * np.exp(z3es * (t - RTT) / (t - z4es))
                 esdp = np.minimum(foeew / ap, e["ZQMAX"])
             else:
@@ -274,7 +298,7 @@ def cloudsc2_nl(fields: Dict[str, np.ndarray], in_eta: np.ndarray, dt, externals
             # :166-186
             crh2 = _crh2(eta[k], tmp_trpaus)
             # :189-193
-            qsat = np.where(t < e["RTICE"], qs_in * (1.8 - 0.003 * t), qs_in)
+            qsat = _where(t < e["RTICE"], qs_in * (1.8 - 0.003 * t), qs_in)
             qcrit = crh2 * qsat
             # :196-207
             qt = q + ql + qi
@@ -283,16 +307,25 @@ def cloudsc2_nl(fields: Dict[str, np.ndarray], in_eta: np.ndarray, dt, externals
             qpd = qsat - qt
             qcd = qsat - qcrit
             clc_p = 1.0 - np.sqrt(qpd / (qcd - scalm * (qt - qcrit)))
-            clc = np.where(clear, 0.0, np.where(overcast, 1.0, clc_p))
-            qc = np.where(clear, 0.0, np.where(
+            _count(bc, "clear", clear)
+            _count(bc, "overcast", overcast)
+            _count(bc, "partial", ~clear & ~overcast)
+            _count(bc, "cold_fwat", t < RTT)
+            _count(bc, "ice_supersaturation", t < e["RTICE"])
+            if e["LPHYLIN"] or e["LDRAIN1D"]:
+                _count(bc, "esdp_clipped", foeew / ap > e["ZQMAX"])
+            clc = _where(clear, 0.0, _where(overcast, 1.0, clc_p))
+            qc = _where(clear, 0.0, _where(
                 overcast, (1.0 - scalm) * (qsat - qcrit),
                 (scalm * qpd + (1.0 - scalm) * qcd) * (clc_p ** 2.0)))
             # :210-215
             gdp = RG / (in_aph[k + 1] - in_aph[k])
             lude = dt * in_lude[k] * gdp
             lo1 = (lude >= e["RLMIN"]) & (in_lu[k + 1] >= ZEPS2)
-            clc = np.where(lo1, clc + (1.0 - clc) * (1.0 - np.exp(-lude / in_lu[k + 1])), clc)
-            qc = np.where(lo1, qc + lude, qc)
+            _count(bc, "detrainment", lo1)
+            _count(bc, "detrainment_without_updraught_condensate", (lude >= e["RLMIN"]) & ~lo1)
+            clc = _where(lo1, clc + (1.0 - clc) * (1.0 - np.exp(-lude / in_lu[k + 1])), clc)
+            qc = _where(lo1, qc + lude, qc)
             # :218-224
             rho = ap / (e["RD"] * t)
             rodqsdp = -rho * qs_in / (ap - e["RETV"] * foeew)
@@ -300,6 +333,8 @@ def cloudsc2_nl(fields: Dict[str, np.ndarray], in_eta: np.ndarray, dt, externals
             dtdzmo = RG * (1.0 / RCPD - ldcp * rodqsdp) / (1.0 + ldcp * dqsdtemp)
             dqsdz = dqsdtemp * dtdzmo - RG * rodqsdp
             dqc = np.minimum(dt * dqsdz * (in_mfu[k] + in_mfd[k]) / rho, qc)
+            _count(bc, "subsidence_evaporates_all_condensate", (dqc >= qc) & (qc > 0.0))
+            _count(bc, "subsidence_evaporates_part", (dqc < qc) & (dqc > 0.0))
             qc = qc - dqc
             # :227-230
             qlwc = qc * fwat
@@ -313,26 +348,34 @@ def cloudsc2_nl(fields: Dict[str, np.ndarray], in_eta: np.ndarray, dt, externals
             melt = tmp_sfl != 0.0
             cons = cons2 * dp / lfdcp
             snmlt = np.minimum(tmp_sfl, cons * np.maximum(t - meltp2, 0.0))
-            rfln = np.where(melt, tmp_rfl + snmlt, tmp_rfl)
-            sfln = np.where(melt, tmp_sfl - snmlt, tmp_sfl)
-            t = np.where(melt, t - snmlt / cons, t)
+            _count(bc, "snow_enters_level", melt)
+            _count(bc, "melting", melt & (snmlt > 0.0))
+            _count(bc, "melting_all_snow", melt & (snmlt > 0.0) & (snmlt >= tmp_sfl))
+            _count(bc, "melting_part_of_snow", melt & (snmlt > 0.0) & (snmlt < tmp_sfl))
+            rfln = _where(melt, tmp_rfl + snmlt, tmp_rfl)
+            sfln = _where(melt, tmp_sfl - snmlt, tmp_sfl)
+            t = _where(melt, t - snmlt / cons, t)
             # :249-272
             cloudy = clc > ZEPS2
             lcrit = 1.9 * e["RCLCRIT"] if LEV else 2.0 * e["RCLCRIT"]
             cldl = qlwc / clc
             dl = ckcodtl * (1.0 - np.exp(-((cldl / lcrit) ** 2.0)))
-            prr = np.where(cloudy, qlwc - clc * cldl * np.exp(-dl), 0.0)
-            qlwc = np.where(cloudy, qlwc - prr, qlwc)
+            prr = _where(cloudy, qlwc - clc * cldl * np.exp(-dl), 0.0)
+            qlwc = _where(cloudy, qlwc - prr, qlwc)
             icrit = 0.0001 if LEV else 2.0 * e["RCLCRIT"]
             cldi = qiwc / clc
             di = ckcodti * np.exp(0.025 * (t - RTT)) * (1.0 - np.exp(-((cldi / icrit) ** 2.0)))
-            prs = np.where(cloudy, qiwc - clc * cldi * np.exp(-di), 0.0)
-            qiwc = np.where(cloudy, qiwc - prs, qiwc)
+            prs = _where(cloudy, qiwc - clc * cldi * np.exp(-di), 0.0)
+            qiwc = _where(cloudy, qiwc - prs, qiwc)
             # :275-285
             dr = cons2 * dp * (prr + prs)
             frz = t < RTT
-            rfreeze = np.where(frz, cons2 * dp * prr, 0.0)
-            fwatr = np.where(frz, 0.0, 1.0)
+            _count(bc, "autoconversion", cloudy)
+            _count(bc, "new_precip_as_snow", frz & (dr > 0.0))
+            _count(bc, "new_precip_as_rain", ~frz & (dr > 0.0))
+            _count(bc, "rain_refreezes", frz & (prr > 0.0))
+            rfreeze = _where(frz, cons2 * dp * prr, 0.0)
+            fwatr = _where(frz, 0.0, 1.0)
             rfln = rfln + fwatr * dr
             sfln = sfln + (1.0 - fwatr) * dr
             # :288-321
@@ -347,11 +390,13 @@ def cloudsc2_nl(fields: Dict[str, np.ndarray], in_eta: np.ndarray, dt, externals
                 dtgdp = dt * RG / (in_aph[k + 1] - in_aph[k])
                 dpr = np.minimum(covpclr * b / dtgdp, preclr)
                 preclr = preclr - dpr
-                tmp_covptot = np.where(ev & (preclr <= 0.0), clc, tmp_covptot)
-                out_covptot_k = np.where(ev, tmp_covptot, 0.0)
-                evapr = np.where(ev, dpr * rfln / prtot, 0.0)
+                _count(bc, "evaporation", ev)
+                _count(bc, "evaporation_of_all_precip", ev & (preclr <= 0.0))
+                tmp_covptot = _where(ev & (preclr <= 0.0), clc, tmp_covptot)
+                out_covptot_k = _where(ev, tmp_covptot, 0.0)
+                evapr = _where(ev, dpr * rfln / prtot, 0.0)
                 rfln = rfln - evapr
-                evaps = np.where(ev, dpr * sfln / prtot, 0.0)
+                evaps = _where(ev, dpr * sfln / prtot, 0.0)
                 sfln = sfln - evaps
             else:
                 out_covptot_k = np.zeros(nx, dtype)
@@ -367,13 +412,20 @@ def cloudsc2_nl(fields: Dict[str, np.ndarray], in_eta: np.ndarray, dt, externals
             q = q + dt * dqdt
             qold = q
             # :347
+            t_pre = t
             t, q = f_cuadjtqs_nl(ap, t, q, e)
             # :350-364
             dq = np.maximum(qold - q, 0.0)
             dr2 = cons2 * dp * dq
             frz2 = t < RTT
-            rfreeze2 = np.where(frz2, fwat * dr2, 0.0)
-            fwatr = np.where(frz2, 0.0, 1.0)
+            _count(bc, "adjustment_condenses", dq > 0.0)
+            _count(bc, "adjustment_evaporates", qold < q)
+            _count(bc, "adjustment_warm_branch", t_pre > RTT)
+            _count(bc, "adjustment_crosses_RTT", (t_pre > RTT) != (t > RTT))
+            _count(bc, "adjustment_precip_as_snow", frz2 & (dq > 0.0))
+            _count(bc, "adjustment_precip_as_rain", ~frz2 & (dq > 0.0))
+            rfreeze2 = _where(frz2, fwat * dr2, 0.0)
+            fwatr = _where(frz2, 0.0, 1.0)
             rn = fwatr * dr2
             sn = (1.0 - fwatr) * dr2
             condl = condl + fwatr * dq / dt
@@ -418,8 +470,8 @@ def _cuadjtqs_tl_0(ap, ap_i, t, t_i, q, q_i, z3es, z4es, z5alcp, zaldcp, e):
     qsat = qp * foeew
     qsat_i = qp_i * foeew + qp * foeew_i
     clip = qsat > e["ZQMAX"]
-    qsat = np.where(clip, e["ZQMAX"], qsat)
-    qsat_i = np.where(clip, 0.0, qsat_i)
+    qsat = _where(clip, e["ZQMAX"], qsat)
+    qsat_i = _where(clip, 0.0, qsat_i)
     cor = 1.0 / (1.0 - e["RETV"] * qsat)
     cor_i = e["RETV"] * qsat_i / (1.0 - e["RETV"] * qsat) ** 2.0
     qsat_i = qsat_i * cor + qsat * cor_i
@@ -441,10 +493,10 @@ def f_cuadjtqs_tl(ap, ap_i, t, t_i, q, q_i, e):
     """tangent_linear/_stencils/cuadjtqs.py:55-84"""
     assert e["ICALL"] == 0
     warm = t > e["RTT"]
-    z3es = np.where(warm, e["R3LES"], e["R3IES"])
-    z4es = np.where(warm, e["R4LES"], e["R4IES"])
-    z5alcp = np.where(warm, e["R5ALVCP"], e["R5ALSCP"])
-    zaldcp = np.where(warm, e["RALVDCP"], e["RALSDCP"])
+    z3es = _where(warm, e["R3LES"], e["R3IES"])
+    z4es = _where(warm, e["R4LES"], e["R4IES"])
+    z5alcp = _where(warm, e["R5ALVCP"], e["R5ALSCP"])
+    zaldcp = _where(warm, e["RALVDCP"], e["RALSDCP"])
     t, t_i, q, q_i = _cuadjtqs_tl_0(ap, ap_i, t, t_i, q, q_i, z3es, z4es, z5alcp, zaldcp, e)
     t, t_i, q, q_i = _cuadjtqs_tl_0(ap, ap_i, t, t_i, q, q_i, z3es, z4es, z5alcp, zaldcp, e)
     return t, t_i, q, q_i
@@ -460,6 +512,7 @@ def cloudsc2_tl(fields: Dict[str, np.ndarray], in_eta: np.ndarray, dt, externals
     in_mfd, in_mfd_i, in_mfu, in_mfu_i = F["in_mfd"], F["in_mfd_i"], F["in_mfu"], F["in_mfu_i"]
     in_qsat, in_qsat_i = F["in_qsat"], F["in_qsat_i"]
     dtype = in_ap.dtype
+    _WORK["dtype"] = dtype
     nz = in_ap.shape[0] - 1
     nx = in_ap.shape[1]
     dt = dtype.type(dt)
@@ -520,17 +573,17 @@ def cloudsc2_tl(fields: Dict[str, np.ndarray], in_eta: np.ndarray, dt, externals
             lvdcp, lvdcp_i = RLVTT * zz, RLVTT * zz_i
             # :189-205
             cold = t < RTT
-            fwat = np.where(cold, 0.545 * (np.tanh(0.17 * (t - e["RLPTRC"])) + 1.0), 1.0)
-            fwat_i = np.where(cold, 0.545 * 0.17 * t_i / np.cosh(0.17 * (t - e["RLPTRC"])) ** 2.0, 0.0)
-            z3es = np.where(cold, e["R3IES"], e["R3LES"])
-            z4es = np.where(cold, e["R4IES"], e["R4LES"])
+            fwat = _where(cold, 0.545 * (np.tanh(0.17 * (t - e["RLPTRC"])) + 1.0), 1.0)
+            fwat_i = _where(cold, 0.545 * 0.17 * t_i / np.cosh(0.17 * (t - e["RLPTRC"])) ** 2.0, 0.0)
+            z3es = _where(cold, e["R3IES"], e["R3LES"])
+            z4es = _where(cold, e["R4IES"], e["R4LES"])
             foeew = e["R2ES"] * np.exp(z3es * (t - RTT) / (t - z4es))
             foeew_i = z3es * (RTT - z4es) * t_i * foeew / (t - z4es) ** 2.0
             esdp = foeew / ap
             esdp_i = foeew_i / ap - foeew * ap_i / (ap ** 2.0)
             clip = esdp > ZQMAX
-            esdp = np.where(clip, ZQMAX, esdp)
-            esdp_i = np.where(clip, 0.0, esdp_i)
+            esdp = _where(clip, ZQMAX, esdp)
+            esdp_i = _where(clip, 0.0, esdp_i)
             # :207-222
             facw = e["R5LES"] / (t - e["R4LES"]) ** 2.0
             facw_i = -2.0 * e["R5LES"] * t_i / (t - e["R4LES"]) ** 3.0
@@ -546,14 +599,14 @@ def cloudsc2_tl(fields: Dict[str, np.ndarray], in_eta: np.ndarray, dt, externals
             corqs_i = cons3 * dqsdtemp_i
             # :225-230
             qgt = q > qs_in
-            qlim = np.where(qgt, qs_in, q)
-            qlim_i = np.where(qgt, qs_in_i, q_i)
+            qlim = _where(qgt, qs_in, q)
+            qlim_i = _where(qgt, qs_in_i, q_i)
             # :233-253
             crh2 = _crh2(eta[k], tmp_trpaus)
             # :256-265
             vcold = t < e["RTICE"]
-            supsat = np.where(vcold, 1.8 - 0.003 * t, 1.0)
-            supsat_i = np.where(vcold, -0.003 * t_i, 0.0)
+            supsat = _where(vcold, 1.8 - 0.003 * t, 1.0)
+            supsat_i = _where(vcold, -0.003 * t_i, 0.0)
             qsat = qs_in * supsat
             qsat_i = qs_in_i * supsat + qs_in * supsat_i
             qcrit = crh2 * qsat
@@ -581,10 +634,10 @@ def cloudsc2_tl(fields: Dict[str, np.ndarray], in_eta: np.ndarray, dt, externals
             qc_p = (scalm * qpd + (1.0 - scalm) * qcd) * clc_p ** 2.0
             qc_p_i = ((scalm * qpd_i + (1.0 - scalm) * qcd_i) * clc_p ** 2.0
                       + 2.0 * (scalm * qpd + (1.0 - scalm) * qcd) * clc_p * clc_p_i)
-            clc = np.where(clear, 0.0, np.where(overcast, 1.0, clc_p))
-            clc_i = np.where(partial, clc_p_i, 0.0)
-            qc = np.where(clear, 0.0, np.where(overcast, (1.0 - scalm) * (qsat - qcrit), qc_p))
-            qc_i = np.where(clear, 0.0, np.where(overcast, (1.0 - scalm) * (qsat_i - qcrit_i), qc_p_i))
+            clc = _where(clear, 0.0, _where(overcast, 1.0, clc_p))
+            clc_i = _where(partial, clc_p_i, 0.0)
+            qc = _where(clear, 0.0, _where(overcast, (1.0 - scalm) * (qsat - qcrit), qc_p))
+            qc_i = _where(clear, 0.0, _where(overcast, (1.0 - scalm) * (qsat_i - qcrit_i), qc_p_i))
             # :309-325
             gdp = RG / (in_aph[k + 1] - in_aph[k])
             gdp_i = -RG * (in_aph_i[k + 1] - in_aph_i[k]) / (in_aph[k + 1] - in_aph[k]) ** 2.0
@@ -592,14 +645,14 @@ def cloudsc2_tl(fields: Dict[str, np.ndarray], in_eta: np.ndarray, dt, externals
             lude_i = dt * (in_lude_i[k] * gdp + in_lude[k] * gdp_i)
             lo1 = (k < NLEV - 1) & (lude >= e["RLMIN"]) & (in_lu[k + 1] >= ZEPS2)
             tmp2 = np.exp(-lude / in_lu[k + 1])
-            clc_i = np.where(
+            clc_i = _where(
                 lo1,
                 clc_i + (-clc_i * (1 - tmp2) + (1.0 - clc) * tmp2
                          * (lude_i / in_lu[k + 1] - lude * in_lu_i[k + 1] / in_lu[k + 1] ** 2.0)),
                 clc_i)
-            clc = np.where(lo1, clc + (1.0 - clc) * (1.0 - tmp2), clc)
-            qc = np.where(lo1, qc + lude, qc)
-            qc_i = np.where(lo1, qc_i + lude_i, qc_i)
+            clc = _where(lo1, clc + (1.0 - clc) * (1.0 - tmp2), clc)
+            qc = _where(lo1, qc + lude, qc)
+            qc_i = _where(lo1, qc_i + lude_i, qc_i)
             # :328-354
             fac1 = 1.0 / (RD * t)
             rho = ap * fac1
@@ -623,8 +676,8 @@ def cloudsc2_tl(fields: Dict[str, np.ndarray], in_eta: np.ndarray, dt, externals
                        - tmp3 * rho_i) / rho
             if LREGCL:
                 dqc_a_i = dqc_a_i * 0.1
-            dqc = np.where(lo3, tmp3, qc)
-            dqc_i = np.where(lo3, dqc_a_i, qc_i)
+            dqc = _where(lo3, tmp3, qc)
+            dqc_i = _where(lo3, dqc_a_i, qc_i)
             qc = qc - dqc
             qc_i = qc_i - dqc_i
             # :376-386
@@ -638,29 +691,29 @@ def cloudsc2_tl(fields: Dict[str, np.ndarray], in_eta: np.ndarray, dt, externals
             condi_i = (qiwc_i - qi_i) / dt
             # :390-397
             up = clc > tmp_covptot
-            tmp_covptot = np.where(up, clc, tmp_covptot)
-            tmp_covptot_i = np.where(up, clc_i, tmp_covptot_i)
+            tmp_covptot = _where(up, clc, tmp_covptot)
+            tmp_covptot_i = _where(up, clc_i, tmp_covptot_i)
             covpclr = tmp_covptot - clc
             covpclr_i = tmp_covptot_i - clc_i
             neg = covpclr < 0.0
-            covpclr = np.where(neg, 0.0, covpclr)
-            covpclr_i = np.where(neg, 0.0, covpclr_i)
+            covpclr = _where(neg, 0.0, covpclr)
+            covpclr_i = _where(neg, 0.0, covpclr_i)
             # :400-427
             melt = tmp_sfl != 0.0
             cons = cons2 * dp / lfdcp
             cons_i = cons2 * (dp_i * lfdcp - dp * lfdcp_i) / lfdcp ** 2
             warm = t > meltp2
-            z2s = np.where(warm, cons * (t - meltp2), 0.0)
-            z2s_i = np.where(warm, cons_i * (t - meltp2) + cons * t_i, 0.0)
+            z2s = _where(warm, cons * (t - meltp2), 0.0)
+            z2s_i = _where(warm, cons_i * (t - meltp2) + cons * t_i, 0.0)
             allm = tmp_sfl <= z2s
-            snmlt = np.where(allm, tmp_sfl, z2s)
-            snmlt_i = np.where(allm, tmp_sfl_i, z2s_i)
-            rfln = np.where(melt, tmp_rfl + snmlt, tmp_rfl)
-            rfln_i = np.where(melt, tmp_rfl_i + snmlt_i, tmp_rfl_i)
-            sfln = np.where(melt, tmp_sfl - snmlt, tmp_sfl)
-            sfln_i = np.where(melt, tmp_sfl_i - snmlt_i, tmp_sfl_i)
-            t_i = np.where(melt, t_i - (snmlt_i * cons - snmlt * cons_i) / cons ** 2, t_i)
-            t = np.where(melt, t - snmlt / cons, t)
+            snmlt = _where(allm, tmp_sfl, z2s)
+            snmlt_i = _where(allm, tmp_sfl_i, z2s_i)
+            rfln = _where(melt, tmp_rfl + snmlt, tmp_rfl)
+            rfln_i = _where(melt, tmp_rfl_i + snmlt_i, tmp_rfl_i)
+            sfln = _where(melt, tmp_sfl - snmlt, tmp_sfl)
+            sfln_i = _where(melt, tmp_sfl_i - snmlt_i, tmp_sfl_i)
+            t_i = _where(melt, t_i - (snmlt_i * cons - snmlt * cons_i) / cons ** 2, t_i)
+            t = _where(melt, t - snmlt / cons, t)
             # :429-503
             cloudy = clc > ZEPS2
             lcrit = 1.9 * e["RCLCRIT"] if LEV else 2.0 * e["RCLCRIT"]
@@ -675,10 +728,10 @@ def cloudsc2_tl(fields: Dict[str, np.ndarray], in_eta: np.ndarray, dt, externals
                 dl_i = (2.0 * ckcodtl / lcrit ** 2.0) * ltmp4 * cldl * cldl_i
             qlnew = clc * cldl * ltmp5
             qlnew_i = clc_i * cldl * ltmp5 + clc * cldl_i * ltmp5 - clc * cldl * ltmp5 * dl_i
-            prr = np.where(cloudy, qlwc - qlnew, 0.0)
-            prr_i = np.where(cloudy, qlwc_i - qlnew_i, 0.0)
-            qlwc = np.where(cloudy, qlwc - prr, qlwc)
-            qlwc_i = np.where(cloudy, qlwc_i - prr_i, qlwc_i)
+            prr = _where(cloudy, qlwc - qlnew, 0.0)
+            prr_i = _where(cloudy, qlwc_i - qlnew_i, 0.0)
+            qlwc = _where(cloudy, qlwc - prr, qlwc)
+            qlwc_i = _where(cloudy, qlwc_i - prr_i, qlwc_i)
             icrit = 0.0001 if LEV else 2.0 * e["RCLCRIT"]
             cldi = qiwc / clc
             cldi_i = qiwc_i / clc - qiwc * clc_i / clc ** 2.0
@@ -690,17 +743,17 @@ def cloudsc2_tl(fields: Dict[str, np.ndarray], in_eta: np.ndarray, dt, externals
                     * (itmp41 * (2.0 * cldi * cldi_i / icrit ** 2.0 - 0.025 * t_i) + 0.025 * t_i))
             qinew = clc * cldi * itmp5
             qinew_i = clc_i * cldi * itmp5 + clc * cldi_i * itmp5 - clc * cldi * itmp5 * di_i
-            prs = np.where(cloudy, qiwc - qinew, 0.0)
-            prs_i = np.where(cloudy, qiwc_i - qinew_i, 0.0)
-            qiwc = np.where(cloudy, qiwc - prs, qiwc)
-            qiwc_i = np.where(cloudy, qiwc_i - prs_i, qiwc_i)
+            prs = _where(cloudy, qiwc - qinew, 0.0)
+            prs_i = _where(cloudy, qiwc_i - qinew_i, 0.0)
+            qiwc = _where(cloudy, qiwc - prs, qiwc)
+            qiwc_i = _where(cloudy, qiwc_i - prs_i, qiwc_i)
             # :506-523
             dr = cons2 * dp * (prr + prs)
             dr_i = cons2 * (dp_i * (prr + prs) + dp * (prr_i + prs_i))
             frz = t < RTT
-            rfreeze = np.where(frz, cons2 * dp * prr, 0.0)
-            rfreeze_i = np.where(frz, cons2 * (dp_i * prr + dp * prr_i), 0.0)
-            fwatr = np.where(frz, 0.0, 1.0)
+            rfreeze = _where(frz, cons2 * dp * prr, 0.0)
+            rfreeze_i = _where(frz, cons2 * (dp_i * prr + dp * prr_i), 0.0)
+            fwatr = _where(frz, 0.0, 1.0)
             fwatr_i = 0.0
             rfln = rfln + fwatr * dr
             rfln_i = rfln_i + fwatr_i * dr + fwatr * dr_i
@@ -735,22 +788,22 @@ def cloudsc2_tl(fields: Dict[str, np.ndarray], in_eta: np.ndarray, dt, externals
                 dpr = covpclr * b / dtgdp
                 dpr_i = (covpclr_i * b + covpclr * b_i) / dtgdp - covpclr * b * dtgdp_i / dtgdp ** 2
                 cap = dpr > preclr
-                dpr = np.where(cap, preclr, dpr)
-                dpr_i = np.where(cap, preclr_i, dpr_i)
+                dpr = _where(cap, preclr, dpr)
+                dpr_i = _where(cap, preclr_i, dpr_i)
                 preclr = preclr - dpr
                 preclr_i = preclr_i - dpr_i
                 reset = ev & (preclr <= 0.0)
-                tmp_covptot = np.where(reset, clc, tmp_covptot)
-                tmp_covptot_i = np.where(reset, clc_i, tmp_covptot_i)
-                out_covptot_k = np.where(ev, tmp_covptot, 0.0)
-                out_covptot_k_i = np.where(ev, tmp_covptot_i, 0.0)
-                evapr = np.where(ev, dpr * rfln / prtot, 0.0)
-                evapr_i = np.where(ev, (dpr_i * rfln + dpr * rfln_i) / prtot
+                tmp_covptot = _where(reset, clc, tmp_covptot)
+                tmp_covptot_i = _where(reset, clc_i, tmp_covptot_i)
+                out_covptot_k = _where(ev, tmp_covptot, 0.0)
+                out_covptot_k_i = _where(ev, tmp_covptot_i, 0.0)
+                evapr = _where(ev, dpr * rfln / prtot, 0.0)
+                evapr_i = _where(ev, (dpr_i * rfln + dpr * rfln_i) / prtot
                                    - dpr * rfln * prtot_i / prtot ** 2, 0.0)
                 rfln = rfln - evapr
                 rfln_i = rfln_i - evapr_i
-                evaps = np.where(ev, dpr * sfln / prtot, 0.0)
-                evaps_i = np.where(ev, (dpr_i * sfln + dpr * sfln_i) / prtot
+                evaps = _where(ev, dpr * sfln / prtot, 0.0)
+                evaps_i = _where(ev, (dpr_i * sfln + dpr * sfln_i) / prtot
                                    - dpr * sfln * prtot_i / prtot ** 2, 0.0)
                 sfln = sfln - evaps
                 sfln_i = sfln_i - evaps_i
@@ -780,15 +833,15 @@ def cloudsc2_tl(fields: Dict[str, np.ndarray], in_eta: np.ndarray, dt, externals
             t, t_i, q, q_i = f_cuadjtqs_tl(ap, ap_i, t, t_i, q, q_i, e)
             # :664-673
             pos = qold >= q
-            dq = np.where(pos, qold - q, 0.0)
-            dq_i = np.where(pos, (qold_i - q_i) * (0.7 if LREGCL else 1.0), 0.0)
+            dq = _where(pos, qold - q, 0.0)
+            dq_i = _where(pos, (qold_i - q_i) * (0.7 if LREGCL else 1.0), 0.0)
             dr2 = cons2 * dp * dq
             dr2_i = cons2 * (dp_i * dq + dp * dq_i)
             # :677-703
             frz2 = t < RTT
-            rfreeze2 = np.where(frz2, fwat * dr2, 0.0)
-            rfreeze2_i = np.where(frz2, fwat_i * dr2 + fwat * dr2_i, 0.0)
-            fwatr = np.where(frz2, 0.0, 1.0)
+            rfreeze2 = _where(frz2, fwat * dr2, 0.0)
+            rfreeze2_i = _where(frz2, fwat_i * dr2 + fwat * dr2_i, 0.0)
+            fwatr = _where(frz2, 0.0, 1.0)
             fwatr_i = 0.0
             rn = fwatr * dr2
             rn_i = fwatr_i * dr2 + fwatr * dr2_i
@@ -854,10 +907,10 @@ def f_cuadjtqs_ad(ap, ap_i, t, t_i, q, q_i, e):
     assert e["ICALL"] == 0
     R2ES, RETV, RTT, ZQMAX = e["R2ES"], e["RETV"], e["RTT"], e["ZQMAX"]
     warm = t > RTT
-    z3es = np.where(warm, e["R3LES"], e["R3IES"])
-    z4es = np.where(warm, e["R4LES"], e["R4IES"])
-    z5alcp = np.where(warm, e["R5ALVCP"], e["R5ALSCP"])
-    zaldcp = np.where(warm, e["RALVDCP"], e["RALSDCP"])
+    z3es = _where(warm, e["R3LES"], e["R3IES"])
+    z4es = _where(warm, e["R4LES"], e["R4IES"])
+    z5alcp = _where(warm, e["R5ALVCP"], e["R5ALSCP"])
+    zaldcp = _where(warm, e["RALVDCP"], e["RALSDCP"])
 
     # :53-71 first iteration ("b")
     targ = t
@@ -865,7 +918,7 @@ def f_cuadjtqs_ad(ap, ap_i, t, t_i, q, q_i, e):
     foeew_b = foeew
     qsat = foeew / ap
     ltest2 = qsat > ZQMAX
-    qsat = np.where(ltest2, ZQMAX, qsat)
+    qsat = _where(ltest2, ZQMAX, qsat)
     cor = 1.0 / (1.0 - RETV * qsat)
     qsat_d = qsat
     qsat = qsat * cor
@@ -881,7 +934,7 @@ def f_cuadjtqs_ad(ap, ap_i, t, t_i, q, q_i, e):
     foeew_a = foeew
     qsat = foeew / ap
     ltest1 = qsat > ZQMAX
-    qsat = np.where(ltest1, ZQMAX, qsat)
+    qsat = _where(ltest1, ZQMAX, qsat)
     cor = 1.0 / (1.0 - RETV * qsat)
     qsat_c = qsat
     qsat = qsat * cor
@@ -906,7 +959,7 @@ def f_cuadjtqs_ad(ap, ap_i, t, t_i, q, q_i, e):
     cor_i = cor_i + qsat_i * qsat
     qsat_i = qsat_i * cor
     qsat_i = qsat_i + cor_i * RETV / (1.0 - RETV * qsat) ** 2.0
-    qsat_i = np.where(ltest1, 0.0, qsat_i)
+    qsat_i = _where(ltest1, 0.0, qsat_i)
     foeew_i = qsat_i / ap
     foeew = foeew_a
     qp_i = qsat_i * foeew
@@ -927,7 +980,7 @@ def f_cuadjtqs_ad(ap, ap_i, t, t_i, q, q_i, e):
     cor_i = cor_i + qsat_i * qsat
     qsat_i = qsat_i * cor
     qsat_i = qsat_i + cor_i * RETV / (1.0 - RETV * qsat) ** 2.0
-    qsat_i = np.where(ltest2, 0.0, qsat_i)
+    qsat_i = _where(ltest2, 0.0, qsat_i)
     foeew_i = qsat_i / ap
     foeew = foeew_b
     qp_i = qp_i + qsat_i * foeew
@@ -955,6 +1008,7 @@ def cloudsc2_ad(fields: Dict[str, np.ndarray], in_eta: np.ndarray, dt, externals
     in_ap, in_aph, in_lu, in_lude = F["in_ap"], F["in_aph"], F["in_lu"], F["in_lude"]
     in_mfd, in_mfu, in_qsat = F["in_mfd"], F["in_mfu"], F["in_qsat"]
     dtype = in_ap.dtype
+    _WORK["dtype"] = dtype
     nz = in_ap.shape[0] - 1
     nx = in_ap.shape[1]
     dt = dtype.type(dt)
@@ -1012,9 +1066,9 @@ def cloudsc2_ad(fields: Dict[str, np.ndarray], in_eta: np.ndarray, dt, externals
             lfdcp, lsdcp, lvdcp = RLMLT / zz, RLSTT / zz, RLVTT / zz
             # :181-197
             cold = t < RTT
-            fwat = np.where(cold, 0.545 * (np.tanh(0.17 * (t2 - e["RLPTRC"])) + 1.0), 1.0)
-            z3es = np.where(cold, e["R3IES"], e["R3LES"])
-            z4es = np.where(cold, e["R4IES"], e["R4LES"])
+            fwat = _where(cold, 0.545 * (np.tanh(0.17 * (t2 - e["RLPTRC"])) + 1.0), 1.0)
+            z3es = _where(cold, e["R3IES"], e["R3LES"])
+            z4es = _where(cold, e["R4IES"], e["R4LES"])
             foeew = e["R2ES"] * np.exp(z3es * (t2 - RTT) / (t2 - z4es))
             esdp1 = foeew / ap
             esdp = np.minimum(esdp1, ZQMAX)
@@ -1026,7 +1080,7 @@ def cloudsc2_ad(fields: Dict[str, np.ndarray], in_eta: np.ndarray, dt, externals
             corqs = 1.0 + cons3 * dqsdtemp
             qlim = np.minimum(q2, qs_in)                        # :200
             crh2 = _crh2(eta[k], tmp_trpaus)                    # :203-223
-            supsat = np.where(t2 < e["RTICE"], 1.8 - 0.003 * t2, 1.0)   # :226-231
+            supsat = _where(t2 < e["RTICE"], 1.8 - 0.003 * t2, 1.0)   # :226-231
             qsat = qs_in * supsat
             qcrit = crh2 * qsat
             # :234-252
@@ -1034,18 +1088,18 @@ def cloudsc2_ad(fields: Dict[str, np.ndarray], in_eta: np.ndarray, dt, externals
             clear = qt <= qcrit
             overcast = (~clear) & (qt >= qsat)
             partial = (~clear) & (~overcast)
-            qcd = np.where(partial, qsat - qcrit, 0.0)
-            qpd = np.where(partial, qsat - qt, 0.0)
-            tmp3 = np.where(partial, np.sqrt(qpd / (qcd - scalm * (qt - qcrit))), 0.0)
-            clc = np.where(clear, 0.0, np.where(overcast, 1.0, 1.0 - tmp3))
-            qc1 = np.where(clear, 0.0, np.where(overcast, (1.0 - scalm) * (qsat - qcrit),
+            qcd = _where(partial, qsat - qcrit, 0.0)
+            qpd = _where(partial, qsat - qt, 0.0)
+            tmp3 = _where(partial, np.sqrt(qpd / (qcd - scalm * (qt - qcrit))), 0.0)
+            clc = _where(clear, 0.0, _where(overcast, 1.0, 1.0 - tmp3))
+            qc1 = _where(clear, 0.0, _where(overcast, (1.0 - scalm) * (qsat - qcrit),
                                                 (scalm * qpd + (1.0 - scalm) * qcd) * clc ** 2.0))
             # :255-263
             gdp = RG / (in_aph[k + 1] - in_aph[k])
             lude = dt * in_lude[k] * gdp
             lo1 = (lude >= e["RLMIN"]) & (in_lu[k + 1] >= ZEPS2)
-            out_clc = np.where(lo1, clc + (1.0 - clc) * (1.0 - np.exp(-lude / in_lu[k + 1])), clc)
-            qc2 = np.where(lo1, qc1 + lude, qc1)
+            out_clc = _where(lo1, clc + (1.0 - clc) * (1.0 - np.exp(-lude / in_lu[k + 1])), clc)
+            qc2 = _where(lo1, qc1 + lude, qc1)
             # :266-277
             fac1 = 1.0 / (RD * t2)
             rho = ap * fac1
@@ -1070,34 +1124,34 @@ def cloudsc2_ad(fields: Dict[str, np.ndarray], in_eta: np.ndarray, dt, externals
             covpclr = np.maximum(covpclr1, 0.0)
             # :293-302
             melt = sfl != 0.0
-            cons = np.where(melt, cons2 * dp / lfdcp, 0.0)
-            z2s = np.where(melt, cons * np.maximum(t2 - meltp2, 0.0), 0.0)
-            snmlt = np.where(melt, np.minimum(sfl, z2s), 0.0)
-            tmp_rfln = np.where(melt, rfl + snmlt, rfl)
-            tmp_sfln = np.where(melt, sfl - snmlt, sfl)
-            t = np.where(melt, t2 - snmlt / cons, t)
+            cons = _where(melt, cons2 * dp / lfdcp, 0.0)
+            z2s = _where(melt, cons * np.maximum(t2 - meltp2, 0.0), 0.0)
+            snmlt = _where(melt, np.minimum(sfl, z2s), 0.0)
+            tmp_rfln = _where(melt, rfl + snmlt, rfl)
+            tmp_sfln = _where(melt, sfl - snmlt, sfl)
+            t = _where(melt, t2 - snmlt / cons, t)
             # :305-337
             cloudy = out_clc > ZEPS2
-            cldl = np.where(cloudy, qlwc1 / out_clc, 0.0)
-            ltmp1 = np.where(cloudy, np.exp(-((cldl / lcrit) ** 2.0)), 0.0)
+            cldl = _where(cloudy, qlwc1 / out_clc, 0.0)
+            ltmp1 = _where(cloudy, np.exp(-((cldl / lcrit) ** 2.0)), 0.0)
             dl = ckcodtl * (1.0 - ltmp1)
-            ltmp2 = np.where(cloudy, np.exp(-dl), 0.0)
+            ltmp2 = _where(cloudy, np.exp(-dl), 0.0)
             qlnew = out_clc * cldl * ltmp2
-            prr = np.where(cloudy, qlwc1 - qlnew, 0.0)
-            qlwc = np.where(cloudy, qlwc1 - prr, qlwc1)
-            cldi = np.where(cloudy, qiwc1 / out_clc, 0.0)
-            itmp11 = np.where(cloudy, np.exp(-((cldi / icrit) ** 2.0)), 0.0)
-            itmp12 = np.where(cloudy, np.exp(0.025 * (t - RTT)), 0.0)
+            prr = _where(cloudy, qlwc1 - qlnew, 0.0)
+            qlwc = _where(cloudy, qlwc1 - prr, qlwc1)
+            cldi = _where(cloudy, qiwc1 / out_clc, 0.0)
+            itmp11 = _where(cloudy, np.exp(-((cldi / icrit) ** 2.0)), 0.0)
+            itmp12 = _where(cloudy, np.exp(0.025 * (t - RTT)), 0.0)
             di = ckcodti * itmp12 * (1.0 - itmp11)
-            itmp2 = np.where(cloudy, np.exp(-di), 0.0)
+            itmp2 = _where(cloudy, np.exp(-di), 0.0)
             qinew = out_clc * cldi * itmp2
-            prs = np.where(cloudy, qiwc1 - qinew, 0.0)
-            qiwc = np.where(cloudy, qiwc1 - prs, qiwc1)
+            prs = _where(cloudy, qiwc1 - qinew, 0.0)
+            qiwc = _where(cloudy, qiwc1 - prs, qiwc1)
             # :340-353
             dr1 = cons2 * dp * (prr + prs)
             frz = t < RTT
-            rfreeze1 = np.where(frz, cons2 * dp * prr, 0.0)
-            fwatr1 = np.where(frz, 0.0, 1.0)
+            rfreeze1 = _where(frz, cons2 * dp * prr, 0.0)
+            fwatr1 = _where(frz, 0.0, 1.0)
             tmp_rfln = tmp_rfln + fwatr1 * dr1
             tmp_sfln = tmp_sfln + (1.0 - fwatr1) * dr1
             rfln2, sfln2 = tmp_rfln, tmp_sfln
@@ -1115,15 +1169,15 @@ def cloudsc2_ad(fields: Dict[str, np.ndarray], in_eta: np.ndarray, dt, externals
                 dpr1 = covpclr * b / dtgdp
                 dpr = np.minimum(dpr1, preclr1)
                 preclr = preclr1 - dpr
-                covptot = np.where(ev & (preclr <= 0.0), out_clc, covptot)
-                out_covptot = np.where(ev, covptot, 0.0)
-                evapr = np.where(ev, dpr * rfln2 / prtot, 0.0)
+                covptot = _where(ev & (preclr <= 0.0), out_clc, covptot)
+                out_covptot = _where(ev, covptot, 0.0)
+                evapr = _where(ev, dpr * rfln2 / prtot, 0.0)
                 tmp_rfln = tmp_rfln - evapr
-                evaps = np.where(ev, dpr * sfln2 / prtot, 0.0)
+                evaps = _where(ev, dpr * sfln2 / prtot, 0.0)
                 tmp_sfln = tmp_sfln - evaps
                 for n_, v_ in (("preclr1", preclr1), ("qe", qe), ("beta", beta), ("b", b), ("dtgdp", dtgdp),
                                ("dpr1", dpr1), ("dpr", dpr), ("preclr", preclr)):
-                    T[n_][k] = np.where(ev, v_, 0.0)
+                    T[n_][k] = _where(ev, v_, 0.0)
             else:
                 evapr = np.zeros(nx, dtype)
                 evaps = np.zeros(nx, dtype)
@@ -1142,8 +1196,8 @@ def cloudsc2_ad(fields: Dict[str, np.ndarray], in_eta: np.ndarray, dt, externals
             dq = np.maximum(qold1 - q, 0.0)
             dr2 = cons2 * dp * dq
             frz2 = (t < RTT) if FIX else (t3 < RTT)             # Q4: literal = pre-adjustment temperature
-            rfreeze2 = np.where(frz2, fwat * dr2, 0.0)
-            fwatr2 = np.where(frz2, 0.0, 1.0)
+            rfreeze2 = _where(frz2, fwat * dr2, 0.0)
+            fwatr2 = _where(frz2, 0.0, 1.0)
             rn = fwatr2 * dr2
             sn = (1.0 - fwatr2) * dr2
             condl2 = condl1 + fwatr2 * dq / dt
@@ -1254,15 +1308,15 @@ def cloudsc2_ad(fields: Dict[str, np.ndarray], in_eta: np.ndarray, dt, externals
             dq_i = (fwatr2 * condl_i + (1.0 - fwatr2) * condi_i) / dt
             dr2_i = fwatr2 * rn_i + (1.0 - fwatr2) * sn_i
             c577 = (g("t") < RTT) if FIX else (g("t3") < RTT)
-            fwat_i = np.where(c577, fwat_i + g("dr2") * rfreeze_i, fwat_i)
-            dr2_i = np.where(c577, dr2_i + fwat * rfreeze_i, dr2_i)
+            fwat_i = _where(c577, fwat_i + g("dr2") * rfreeze_i, fwat_i)
+            dr2_i = _where(c577, dr2_i + fwat * rfreeze_i, dr2_i)
             dq_i = dq_i + cons2 * dp * dr2_i
             dp_i = cons2 * g("dq") * dr2_i
             pos = g("qold1") >= g("q")
             if LREGCL:
-                dq_i = np.where(pos, dq_i * 0.7, dq_i)
-            qold_i = np.where(pos, dq_i, 0.0)
-            o_q = np.where(pos, -dq_i, 0.0)
+                dq_i = _where(pos, dq_i * 0.7, dq_i)
+            qold_i = _where(pos, dq_i, 0.0)
+            o_q = _where(pos, -dq_i, 0.0)
             # :594-598
             o_ap, _t, o_t, _q, o_q = f_cuadjtqs_ad(ap, np.zeros(nx, dtype), g("told"), np.zeros(nx, dtype),
                                                    g("qold"), o_q, e)
@@ -1308,11 +1362,11 @@ def cloudsc2_ad(fields: Dict[str, np.ndarray], in_eta: np.ndarray, dt, externals
                 dpr_i = dpr_i + rfln2 * e_evapr_i / prtot
                 prtot_i = prtot_i - dpr * rfln2 * e_evapr_i / prtot ** 2.0
                 cov_i = covptot_i3[k + 1] + a_covptot[k]
-                e_clc = np.where(preclr <= 0, a_clc_k + cov_i, a_clc_k)
-                cov_i = np.where(preclr <= 0, 0.0, cov_i)
+                e_clc = _where(preclr <= 0, a_clc_k + cov_i, a_clc_k)
+                cov_i = _where(preclr <= 0, 0.0, cov_i)
                 capped = dpr1 > preclr1
-                preclr_i = np.where(capped, dpr_i, 0.0)
-                dpr_i = np.where(capped, 0.0, dpr_i)
+                preclr_i = _where(capped, dpr_i, 0.0)
+                dpr_i = _where(capped, 0.0, dpr_i)
                 b_i = covpclr * dpr_i / dtgdp
                 covpclr_i = b * dpr_i / dtgdp
                 dtgdp_i = -covpclr * b * dpr_i / dtgdp ** 2.0
@@ -1338,20 +1392,20 @@ def cloudsc2_ad(fields: Dict[str, np.ndarray], in_eta: np.ndarray, dt, externals
                 prtot_i = prtot_i + covpclr * preclr_i / covptot1
                 cov_i = cov_i - prtot * covpclr * preclr_i / covptot1 ** 2.0
                 # merge with the `else` branch (:711-719)
-                evaps_i = np.where(ev, e_evaps_i, evaps_i)
-                evapr_i = np.where(ev, e_evapr_i, evapr_i)
-                tmp_sfln_i = np.where(ev, e_sfln_i, tmp_sfln_i)
-                tmp_rfln_i = np.where(ev, e_rfln_i, tmp_rfln_i)
-                a_clc_k = np.where(ev, e_clc, a_clc_k)
-                o_ap = np.where(ev, e_ap, o_ap)
-                tmp_aph_s_i = np.where(ev, e_aphs, tmp_aph_s_i)
-                corqs_i = np.where(ev, corqs_i, 0.0)
-                covpclr_i = np.where(ev, covpclr_i, 0.0)
-                covptot_i = np.where(ev, cov_i, 0.0)
-                daph_i = np.where(ev, daph_i, 0.0)
-                o_qsat = np.where(ev, o_qsat, 0.0)
-                prtot_i = np.where(ev, prtot_i, 0.0)
-                qlim_i = np.where(ev, qlim_i, 0.0)
+                evaps_i = _where(ev, e_evaps_i, evaps_i)
+                evapr_i = _where(ev, e_evapr_i, evapr_i)
+                tmp_sfln_i = _where(ev, e_sfln_i, tmp_sfln_i)
+                tmp_rfln_i = _where(ev, e_rfln_i, tmp_rfln_i)
+                a_clc_k = _where(ev, e_clc, a_clc_k)
+                o_ap = _where(ev, e_ap, o_ap)
+                tmp_aph_s_i = _where(ev, e_aphs, tmp_aph_s_i)
+                corqs_i = _where(ev, corqs_i, 0.0)
+                covpclr_i = _where(ev, covpclr_i, 0.0)
+                covptot_i = _where(ev, cov_i, 0.0)
+                daph_i = _where(ev, daph_i, 0.0)
+                o_qsat = _where(ev, o_qsat, 0.0)
+                prtot_i = _where(ev, prtot_i, 0.0)
+                qlim_i = _where(ev, qlim_i, 0.0)
             else:
                 corqs_i = np.zeros(nx, dtype)
                 covpclr_i = np.zeros(nx, dtype)
@@ -1367,8 +1421,8 @@ def cloudsc2_ad(fields: Dict[str, np.ndarray], in_eta: np.ndarray, dt, externals
             dr_i = fwatr1 * tmp_rfln_i + (1.0 - fwatr1) * tmp_sfln_i
             prr, prs = g("prr"), g("prs")
             c729 = (fwatr1 == 0.0) if FIX else (g("t") < RTT)     # Q5: literal = post-adjustment temperature
-            dp_i = np.where(c729, dp_i + rfreeze_i * cons2 * prr, dp_i)
-            prr_i = np.where(c729, rfreeze_i * cons2 * dp, 0.0)
+            dp_i = _where(c729, dp_i + rfreeze_i * cons2 * prr, dp_i)
+            prr_i = _where(c729, rfreeze_i * cons2 * dp, 0.0)
             prr_i = prr_i + cons2 * dp * dr_i
             prs_i = cons2 * dp * dr_i
             dp_i = dp_i + cons2 * (prr + prs) * dr_i
@@ -1397,10 +1451,10 @@ def cloudsc2_ad(fields: Dict[str, np.ndarray], in_eta: np.ndarray, dt, externals
             cldl_i = cldl_i + 2.0 * ltmp4 * ltmp1 * cldl * dl_i / lcrit ** 2.0
             c_qlwc_i = c_qlwc_i + cldl_i / out_clc
             c_clc = c_clc - g("qlwc1") * cldl_i / out_clc ** 2.0
-            qiwc_i = np.where(cloudy, c_qiwc_i, qiwc_i)
-            qlwc_i = np.where(cloudy, c_qlwc_i, qlwc_i)
-            a_clc_k = np.where(cloudy, c_clc, a_clc_k)
-            o_t = np.where(cloudy, c_t, o_t)
+            qiwc_i = _where(cloudy, c_qiwc_i, qiwc_i)
+            qlwc_i = _where(cloudy, c_qlwc_i, qlwc_i)
+            a_clc_k = _where(cloudy, c_clc, a_clc_k)
+            o_t = _where(cloudy, c_t, o_t)
             # :785-806
             sfl = g("sfl")
             melt = sfl != 0.0
@@ -1410,27 +1464,27 @@ def cloudsc2_ad(fields: Dict[str, np.ndarray], in_eta: np.ndarray, dt, externals
             m_rfl_i = tmp_rfln_i
             m_sfl_i = tmp_sfln_i
             allm = sfl <= z2s
-            m_sfl_i = np.where(allm, m_sfl_i + snmlt_i, m_sfl_i)
-            z2s_i = np.where(allm, 0.0, snmlt_i)
+            m_sfl_i = _where(allm, m_sfl_i + snmlt_i, m_sfl_i)
+            z2s_i = _where(allm, 0.0, snmlt_i)
             warm = t2 > meltp2
-            m_t = np.where(warm, o_t + cons * z2s_i, o_t)
-            cons_i = np.where(warm, cons_i + (t2 - meltp2) * z2s_i, cons_i)
+            m_t = _where(warm, o_t + cons * z2s_i, o_t)
+            cons_i = _where(warm, cons_i + (t2 - meltp2) * z2s_i, cons_i)
             m_dp_i = dp_i + cons2 * cons_i / lfdcp
             m_lfdcp_i = -cons2 * dp * cons_i / lfdcp ** 2.0
-            rfl_i3[k] = np.where(melt, m_rfl_i, 0.0)
-            sfl_i3[k] = np.where(melt, m_sfl_i, 0.0)
-            tmp_rfln_i = np.where(melt, 0.0, tmp_rfln_i)
-            tmp_sfln_i = np.where(melt, 0.0, tmp_sfln_i)
-            o_t = np.where(melt, m_t, o_t)
-            dp_i = np.where(melt, m_dp_i, dp_i)
-            lfdcp_i = np.where(melt, m_lfdcp_i, 0.0)
+            rfl_i3[k] = _where(melt, m_rfl_i, 0.0)
+            sfl_i3[k] = _where(melt, m_sfl_i, 0.0)
+            tmp_rfln_i = _where(melt, 0.0, tmp_rfln_i)
+            tmp_sfln_i = _where(melt, 0.0, tmp_sfln_i)
+            o_t = _where(melt, m_t, o_t)
+            dp_i = _where(melt, m_dp_i, dp_i)
+            lfdcp_i = _where(melt, m_lfdcp_i, 0.0)
             # :810-817
-            covpclr_i = np.where(g("covpclr1") < 0.0, 0.0, covpclr_i)
+            covpclr_i = _where(g("covpclr1") < 0.0, 0.0, covpclr_i)
             covptot_i = covptot_i + covpclr_i
             a_clc_k = a_clc_k - covpclr_i
             c815 = out_clc > g("covptot")
-            a_clc_k = np.where(c815, a_clc_k + covptot_i, a_clc_k)
-            covptot_i = np.where(c815, 0.0, covptot_i)
+            a_clc_k = _where(c815, a_clc_k + covptot_i, a_clc_k)
+            covptot_i = _where(c815, 0.0, covptot_i)
             covptot_i3[k] = covptot_i
             # :820-825
             qiwc_i = qiwc_i + condi_i / dt
@@ -1444,11 +1498,11 @@ def cloudsc2_ad(fields: Dict[str, np.ndarray], in_eta: np.ndarray, dt, externals
             fac4, dqsdz = g("fac4"), g("dqsdz")
             dqc_i = -qc_i
             l_dqc_i = dqc_i * 0.1 if LREGCL else dqc_i
-            dqsdz_i = np.where(lo3, dt * l_dqc_i * (in_mfd[k] + in_mfu[k]) * fac4, 0.0)
-            o_mfd = np.where(lo3, dt * l_dqc_i * dqsdz * fac4, 0.0)
+            dqsdz_i = _where(lo3, dt * l_dqc_i * (in_mfd[k] + in_mfu[k]) * fac4, 0.0)
+            o_mfd = _where(lo3, dt * l_dqc_i * dqsdz * fac4, 0.0)
             o_mfu = o_mfd
-            rho_i = np.where(lo3, -l_dqc_i * g("dqc") * fac4, 0.0)
-            qc_i = np.where(lo3, qc_i, qc_i + dqc_i)
+            rho_i = _where(lo3, -l_dqc_i * g("dqc") * fac4, 0.0)
+            qc_i = _where(lo3, qc_i, qc_i + dqc_i)
             # :844-855
             dqsdtemp, dtdzmo, ldcp, fac3 = g("dqsdtemp"), g("dtdzmo"), g("ldcp"), g("fac3")
             rodqsdp, fac2, fac1, rho = g("rodqsdp"), g("fac2"), g("fac1"), g("rho")
@@ -1469,9 +1523,9 @@ def cloudsc2_ad(fields: Dict[str, np.ndarray], in_eta: np.ndarray, dt, externals
             lu1 = in_lu[k + 1]
             lo1 = (k < NLEV - 1) & (lude >= e["RLMIN"]) & (lu1 >= ZEPS2)
             ex = np.exp(-lude / lu1)
-            lude_i = np.where(lo1, qc_i + (1.0 - clc) / lu1 * ex * a_clc_k, 0.0)
-            dlu_i = np.where(lo1, (1.0 - clc) * lude / lu1 ** 2.0 * ex * a_clc_k, 0.0)
-            a_clc_k = np.where(lo1, a_clc_k * (1.0 - (1.0 - ex)), a_clc_k)
+            lude_i = _where(lo1, qc_i + (1.0 - clc) / lu1 * ex * a_clc_k, 0.0)
+            dlu_i = _where(lo1, (1.0 - clc) * lude / lu1 ** 2.0 * ex * a_clc_k, 0.0)
+            a_clc_k = _where(lo1, a_clc_k * (1.0 - (1.0 - ex)), a_clc_k)
             o_lude = o_lude + dt * gdp * lude_i
             gdp_i = gdp_i + dt * lude_in * lude_i
             daph_i = daph_i + RG * gdp_i / (in_aph[k + 1] - in_aph[k]) ** 2.0
@@ -1494,9 +1548,9 @@ def cloudsc2_ad(fields: Dict[str, np.ndarray], in_eta: np.ndarray, dt, externals
             p_qt_i = (-0.5 / tmp3 * (qpd * scalm * p_clc) / den ** 2.0) - p_qpd_i
             p_qcrit_i = (0.5 / tmp3 * (qpd * scalm * p_clc) / den ** 2.0) - p_qcd_i
             p_qsat_i = p_qcd_i + p_qpd_i
-            qt_i = np.where(partial, p_qt_i, 0.0)
-            qsat_i = np.where(clear, 0.0, np.where(overcast, (1.0 - scalm) * qc_i, p_qsat_i))
-            qcrit_i = np.where(clear, 0.0, np.where(overcast, -(1.0 - scalm) * qc_i, p_qcrit_i))
+            qt_i = _where(partial, p_qt_i, 0.0)
+            qsat_i = _where(clear, 0.0, _where(overcast, (1.0 - scalm) * qc_i, p_qsat_i))
+            qcrit_i = _where(clear, 0.0, _where(overcast, -(1.0 - scalm) * qc_i, p_qcrit_i))
             # :920-938
             o_q = o_q + qt_i
             o_ql = o_ql + qt_i
@@ -1504,10 +1558,10 @@ def cloudsc2_ad(fields: Dict[str, np.ndarray], in_eta: np.ndarray, dt, externals
             qsat_i = qsat_i + qcrit_i * g("crh2")
             o_qsat = o_qsat + qsat_i * g("supsat")
             supsat_i = qsat_i * qs_in
-            o_t = np.where(t2 < e["RTICE"], o_t - 0.003 * supsat_i, o_t)
+            o_t = _where(t2 < e["RTICE"], o_t - 0.003 * supsat_i, o_t)
             qgt = g("q2") > qs_in
-            o_qsat = np.where(qgt, o_qsat + qlim_i, o_qsat)
-            o_q = np.where(qgt, o_q, o_q + qlim_i)
+            o_qsat = _where(qgt, o_qsat + qlim_i, o_qsat)
+            o_q = _where(qgt, o_q, o_q + qlim_i)
             # :941-967
             fac, cor, facw, faci, foeew = g("fac"), g("cor"), g("facw"), g("faci"), g("foeew")
             dqsdtemp_i = dqsdtemp_i + cons3 * corqs_i
@@ -1520,14 +1574,14 @@ def cloudsc2_ad(fields: Dict[str, np.ndarray], in_eta: np.ndarray, dt, externals
             fwat_i = fwat_i + (facw - faci) * fac_i
             o_t = o_t - 2.0 * (e["R5IES"] * faci_i / (t2 - e["R4IES"]) ** 3.0
                                + e["R5LES"] * facw_i / (t2 - e["R4LES"]) ** 3.0)
-            esdp_i = np.where(g("esdp1") > ZQMAX, 0.0, esdp_i)
+            esdp_i = _where(g("esdp1") > ZQMAX, 0.0, esdp_i)
             foeew_i = foeew_i + esdp_i / ap
             o_ap = o_ap - esdp_i * foeew / ap ** 2.0
             cold = t2 < RTT
-            z3es = np.where(cold, e["R3IES"], e["R3LES"])
-            z4es = np.where(cold, e["R4IES"], e["R4LES"])
+            z3es = _where(cold, e["R3IES"], e["R3LES"])
+            z4es = _where(cold, e["R4IES"], e["R4LES"])
             o_t = o_t + z3es * (RTT - z4es) * foeew_i * foeew / (t2 - z4es) ** 2.0
-            o_t = np.where(cold, o_t + 0.545 * 0.17 * fwat_i / np.cosh(0.17 * (t2 - e["RLPTRC"])) ** 2.0, o_t)
+            o_t = _where(cold, o_t + 0.545 * 0.17 * fwat_i / np.cosh(0.17 * (t2 - e["RLPTRC"])) ** 2.0, o_t)
             # keep what later computations read
             daph_i3[k], dp_i3[k], dlu_i3[k] = daph_i, dp_i, dlu_i
             lvdcp_i3[k], lsdcp_i3[k], lfdcp_i3[k] = lvdcp_i, lsdcp_i, lfdcp_i

@@ -16,7 +16,11 @@ semantics summarised in SURVEY.md 8(c):
   * `f[0, 0, dk]` / `f[0, 0]` / `f[dk]` address 3-D / IJ / K fields; a bare field name means offset 0;
   * `@gtscript.function`s are inlined (arguments by value, `from __externals__ import ...` resolved
     from the same externals dict), including functions returning tuples;
-  * `**` is `np.power`, `exp/tanh/cosh/sqrt/min/max/abs` map to NumPy.
+  * `**` is `np.power`, `exp/tanh/cosh/sqrt/min/max/abs` map to NumPy;
+  * precision (`Executor(dtype=...)`): fields, temporaries, function locals and scalar arguments are held in the field
+    dtype; externals and literals are Python floats, which NumPy treats as weak scalars (they take the precision of the
+    array they meet).  In float64 this is plain double arithmetic; in float32 it is the "every field-valued quantity in
+    single precision" reading of GT4Py's numpy backend.
 
 It is deliberately NOT a GT4Py re-implementation: no backends, no code generation, no storage
 classes - just enough to run `/root/reference/src/cloudsc2_gt4py/physics/**/_stencils/*.py`
@@ -221,9 +225,12 @@ class Executor:
         else:
             name, off = target.id, 0
         assert off == 0, "writes with a vertical offset are not part of the subset"
-        if not top:  # inside an inlined function: plain local
+        if not top:  # inside an inlined function: plain local, held in the field precision like every temporary
             old = local.get(name, 0.0)
-            local[name] = self._masked(old, value, mask)
+            new = self._masked(old, value, mask)
+            if isinstance(new, np.ndarray) and new.dtype.kind == "f" and new.dtype != self.dtype:
+                new = new.astype(self.dtype)
+            local[name] = new
             return
         kind = self.kinds.get(name)
         if kind == "IJK":

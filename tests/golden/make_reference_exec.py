@@ -2,7 +2,8 @@
 /root/reference, never copied) through tests/golden/gtscript_exec.py on seeded synthetic columns.
 
 Run in the build container only:  python tests/golden/make_reference_exec.py
-Writes tests/golden/reference_exec.npz (inputs + outputs; data only).  The GPU box has no
+Writes tests/golden/reference_exec.npz, reference_exec_evap.npz (fp64) and reference_exec_f32.npz (float32 fields:
+the drivers' cases + LEVAPLS2; see main() for the fp32 semantics) - inputs + outputs, data only.  The GPU box has no
 /root/reference, so the tests read the .npz.
 
 What the vectors pin: saturation, cloudsc2_nl (driver flags, and LEVAPLS2=True), cloudsc2_tl
@@ -32,17 +33,36 @@ NL_IN = ("ap", "aph", "lu", "lude", "mfd", "mfu", "q", "qi", "ql", "qsat", "sups
 NL_OUT = ("clc", "covptot", "fhpsl", "fhpsn", "fplsl", "fplsn", "tnd_q", "tnd_qi", "tnd_ql", "tnd_t")
 
 
+DTYPE = np.float64     # field dtype of the run in progress (main() is executed once per precision)
+
+
 def zeros(nx=NX):
-    return np.zeros((NZ + 1, nx))
+    return np.zeros((NZ + 1, nx), DTYPE)
 
 
-def main():
+class _Exec(Executor):
+    """Executor in the precision of the run in progress."""
+
+    def __init__(self, defs, externals):
+        super().__init__(defs, externals, dtype=DTYPE)
+
+
+def main(dtype=np.float64):
+    """dtype=float64: the two fp64 files (every case).  dtype=float32: `reference_exec_f32.npz`, the drivers' cases
+    plus LEVAPLS2, executed with float32 fields.  fp32 semantics of this executor = GT4Py's numpy backend under
+    value-based scalar casting: fields, temporaries and the scalar arguments (`dt`, `f`) are float32; externals and
+    literals are Python floats, i.e. *weak* scalars that take the field's precision in every operation with a field
+    (scalar-only sub-expressions such as RLVTT / RCPD are evaluated in double and rounded once when they meet a field)."""
+    global DTYPE
+    DTYPE = np.dtype(dtype).type
+    f32 = DTYPE is np.float32
+    Executor = _Exec  # noqa: N806 - every stencil run below uses the run's precision
     defs = load_definitions(reference_stencil_files(REFERENCE))
     ext = default_externals()
     ext["NLEV"] = NZ
     dt = DEFAULT_TIMESTEP_S
-    s = make_state(NX, NZ, seed=SEED)
-    eta = eta_levels(NZ, seed=SEED)
+    s = make_state(NX, NZ, seed=SEED, dtype=DTYPE)
+    eta = eta_levels(NZ, seed=SEED, dtype=DTYPE)
     out = {"eta": eta, "dt": np.float64(dt), "nz": np.int64(NZ)}
     ins = {"in_" + k[2:]: v.copy() for k, v in s.items()}
 
@@ -55,7 +75,7 @@ def main():
         out["in_" + n] = ins["in_" + n]
 
     def ij():
-        return np.zeros(NX)
+        return np.zeros(NX, DTYPE)
 
     def run_nl(e, inputs):
         f = {k: v.copy() for k, v in inputs.items()}
@@ -67,7 +87,8 @@ def main():
         Executor(defs, e).run("cloudsc2_nl", f, {"dt": dt}, NZ)
         return {n: f["out_" + n] for n in NL_OUT}
 
-    for tag, e in (("nl", ext), ("nl_evap", {**ext, "LEVAPLS2": True}), ("nl_nolin", {**ext, "LPHYLIN": False})):
+    nl_cases = (("nl", ext), ("nl_evap", {**ext, "LEVAPLS2": True}), ("nl_nolin", {**ext, "LPHYLIN": False}))
+    for tag, e in nl_cases[:2] if f32 else nl_cases:
         r = run_nl(e, ins)
         for n in NL_OUT:
             out[f"{tag}_out_{n}"] = r[n]
@@ -106,8 +127,9 @@ def main():
         return f
 
     evap = {**ext, "LEVAPLS2": True}
-    for tag, e, inc_tag in (("tl", ext, "inc"), ("tl_noreg", {**ext, "LREGCL": False}, "inc"),
-                            ("tl_sym", ext, "inc_nosupsat"), ("tl_evap", evap, "inc_nosupsat")):
+    tl_cases = (("tl", ext, "inc"), ("tl_noreg", {**ext, "LREGCL": False}, "inc"),
+                ("tl_sym", ext, "inc_nosupsat"), ("tl_evap", evap, "inc_nosupsat"))
+    for tag, e, inc_tag in tl_cases[1:3] if f32 else tl_cases:   # fp32: the Taylor test's and the symmetry test's TL
         f = run_tl(e, inc_tag)
         for n in NL_OUT:
             out[f"{tag}_out_{n}"] = f["out_" + n]
@@ -132,16 +154,18 @@ def main():
         Executor(defs, e).run("cloudsc2_ad", f, {"dt": dt}, NZ)
         return f
 
-    for tag, e, tl_tag in (("ad", ext, "tl_sym"), ("ad_noreg", {**ext, "LREGCL": False}, "tl_sym")):
+    ad_cases = (("ad", ext, "tl_sym"), ("ad_noreg", {**ext, "LREGCL": False}, "tl_sym"))
+    for tag, e, tl_tag in ad_cases[:1] if f32 else ad_cases:
         f = run_ad(e, {n: out[f"{tl_tag}_out_{n}_i"] for n in NL_OUT})
         for n in NL_OUT:
             out[f"{tag}_out_{n}"] = f["out_" + n]
         for n in NL_IN:
             out[f"{tag}_out_{n}_i"] = f["out_" + n + "_i"]
 
-    path = os.path.join(HERE, "reference_exec.npz")
-    np.savez_compressed(path, **out)
-    print(path, len(out), "arrays", os.path.getsize(path) // 1024, "KiB")
+    if not f32:
+        path = os.path.join(HERE, "reference_exec.npz")
+        np.savez_compressed(path, **out)
+        print(path, len(out), "arrays", os.path.getsize(path) // 1024, "KiB")
 
     # ---- evaporation block of TL and AD (LEVAPLS2) at dt = 60 s with increments that are NOT proportional to
     # the state: at the drivers' 3600 s the reference's TL recurrence amplifies rounding noise (its b_i carries
@@ -150,8 +174,27 @@ def main():
     ev = {"dt": np.float64(60.0)}
     rng = np.random.default_rng(SEED)
     for n in NL_IN:
-        ev[f"inc_{n}_i"] = 0.01 * ins["in_" + n] * rng.uniform(0.5, 1.5, size=ins["in_" + n].shape)
+        ev[f"inc_{n}_i"] = (0.01 * ins["in_" + n] * rng.uniform(0.5, 1.5, size=ins["in_" + n].shape)).astype(DTYPE)
     ev["inc_supsat_i"][...] = 0.0
+    if f32:
+        # fp32 file: + the evaporation block of TL / AD (LEVAPLS2, LREGCL as the drivers) at dt = 60 s, then done
+        f = run_tl(evap, "inc", dt=60.0, src=ev)
+        for n in NL_IN:
+            out[f"evap60_inc_{n}_i"] = ev[f"inc_{n}_i"]
+        for n in NL_OUT:
+            out[f"evap60_tl_out_{n}"] = f["out_" + n]
+            out[f"evap60_tl_out_{n}_i"] = f["out_" + n + "_i"]
+        f = run_ad(evap, {n: out[f"evap60_tl_out_{n}_i"] for n in NL_OUT}, dt=60.0)
+        for n in NL_OUT:
+            out[f"evap60_ad_out_{n}"] = f["out_" + n]
+        for n in NL_IN:
+            out[f"evap60_ad_out_{n}_i"] = f["out_" + n + "_i"]
+        bad = [k for k, v in out.items() if isinstance(v, np.ndarray) and v.ndim == 2 and v.dtype != np.float32]
+        assert not bad, bad
+        path = os.path.join(HERE, "reference_exec_f32.npz")
+        np.savez_compressed(path, **out)
+        print(path, len(out), "arrays", os.path.getsize(path) // 1024, "KiB")
+        return
     for tag, e in (("tl_evap", evap), ("tl_evap_noreg", {**evap, "LREGCL": False})):
         f = run_tl(e, "inc", dt=60.0, src=ev)
         for n in NL_OUT:
@@ -191,4 +234,5 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    main(np.float64)
+    main(np.float32)

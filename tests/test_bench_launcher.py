@@ -1,0 +1,65 @@
+"""`python bench.py --gpus N` invoked PLAINLY must produce the N-rank line: the parent starts
+`python -m torch.distributed.run` as a child before it touches torch or the GPU and relays rank 0's JSON line.
+Rehearsed here without a GPU through `--dry-run` (gloo, shard bookkeeping and reductions only, no kernels)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(*args, env=None):
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    e.update(env or {})
+    p = subprocess.run([sys.executable, BENCH, *args], capture_output=True, text=True, timeout=600, env=e)
+    return p
+
+
+def test_plain_invocation_with_two_gpus_starts_two_ranks():
+    p = _run("--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run")
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout                       # ONE JSON line on stdout, everything else on stderr
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["steps"] == 3 and d["warmup"] == 1
+    assert d["scaling"] == "weak" and d["dtype"] == "f64" and d["dry_run"] is True and d["value"] is None
+    assert d["config"]["columns_per_gpu"] == 65536 and d["config"]["columns_total"] == 131072
+    # the two ranks own different slices of ONE global problem (col0 = 0 and 65536) and the same eta
+    assert d["shard_check"]["col0_sum"] == 65536.0
+    assert d["shard_check"]["eta_sum_x_world"] == pytest.approx(2 * d["shard_check"]["eta_sum"], rel=1e-12)
+    assert "torch.distributed.run" in p.stderr             # the launcher announced the child it started
+
+
+def test_config5_is_the_fixed_fp32_problem_split_over_the_gpus():
+    p = _run("--gpus", "2", "--config", "5", "--dry-run")
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads(p.stdout.strip().splitlines()[-1])
+    assert d["scaling"] == "strong" and d["dtype"] == "f32" and d["n_gpus"] == 2
+    assert d["config"]["columns_per_gpu"] == 4194304 // 2 and d["config"]["columns_total"] == 4194304
+    assert "configs[4]" in d["config"]["workload"] and "fp32" in d["metric"]
+    q = _run("--gpus", "1", "--config", "5", "--dry-run")
+    assert q.returncode == 0, q.stderr[-3000:]
+    d1 = json.loads(q.stdout.strip().splitlines()[-1])
+    assert d1["config"]["columns_per_gpu"] == 4194304 and d1["n_gpus"] == 1 and d1["rccl_ranks"] is None
+
+
+def test_world_size_mismatch_and_bad_splits_are_refused():
+    p = _run("--gpus", "2", "--dry-run", env={"WORLD_SIZE": "3", "RANK": "0"})
+    assert p.returncode != 0 and "WORLD_SIZE=3" in (p.stderr + p.stdout)
+    p = _run("--gpus", "3", "--config", "5", "--dry-run")
+    assert p.returncode != 0 and "do not split" in p.stderr
+
+
+def test_launcher_parent_never_imports_torch():
+    """The parent of a plain `--gpus N` run must not hold a HIP context when it starts the ranks: it imports nothing
+    beyond the standard library before `launch_ranks` (checked on the module source: no torch import at module level,
+    and main() branches to the launcher before its first torch import)."""
+    src = open(BENCH).read()
+    head = src[:src.index("def parse_args")]
+    assert "import torch" not in head
+    main_src = src[src.index("def main("):]
+    assert main_src.index("launch_ranks(args, argv)") < main_src.index("import torch")

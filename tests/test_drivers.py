@@ -79,38 +79,92 @@ def test_unknown_backend_is_rejected():
 
 # ------------------------------------------------------------------------------------------------ GPU
 @pytest.mark.gpu
-def test_config2_nonlinear_65536(gpu, capsys):
-    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.drivers import run_nonlinear
-
-    ctx = run_nonlinear.main(["--backend", "hip", "--num-cols", "65536", "--num-runs", "5", "--input", "synthetic",
-                              "--disable-validation"])
-    out = capsys.readouterr().out
-    assert "Performance: 65536 columns, 5 runs" in out
-    assert np.mean(ctx["runtimes_ms"]) < 5.0
+@pytest.mark.parametrize("num_cols", [4096, 65536])
+def test_config2_nonlinear_with_golden_comparison(gpu, capsys, num_cols):
+    """BASELINE configs[1] through the driver WITH its validation step (run_nonlinear.py:139-147): `validate()` runs on
+    the HIP output fields against data/reference_double.h5 (its .npz conversion on the GPU box) through the `f_qv -> f_q`
+    mapping.  The golden file's inputs (data/input.h5) are not available, so the comparison of the values says nothing
+    about the kernels; asserted is what the inputs cannot change: every reference field finds its counterpart with the
+    right shape, `f_covptot` agrees exactly (0 without the evaporation block on both sides), and the HIP outputs obey the
+    reference's own identities fhpsn = -RLSTT fplsn, fhpsl = -RLVTT fplsl."""
     import torch
 
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.drivers import run_nonlinear
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.params import default_externals
+
+    ctx = run_nonlinear.main(["--backend", "hip", "--num-cols", str(num_cols), "--num-runs", "5", "--input", "synthetic"])
+    out = capsys.readouterr().out
+    print(out)
+    assert f"Performance: {num_cols} columns, 5 runs" in out and "== Validation:" in out
+    assert np.mean(ctx["runtimes_ms"]) < 5.0
+    rep = ctx["validation"]
+    assert set(rep) == {"f_qi", "f_ql", "f_qv", "f_t", "f_clc", "f_covptot", "f_fhpsl", "f_fhpsn", "f_fplsl", "f_fplsn"}
+    assert rep["f_qv"]["as"] == "f_q"                                   # nonlinear/reference.py:32 vs microphysics.py:106
+    for name, r in rep.items():
+        assert r["shape"] == r["ref_shape"] == (num_cols, 1, 138), (name, r)
+        assert np.isfinite(r["max_abs_err"]), name
+        assert f"  {name:12s}" in out                                    # one printed line per field
+    assert rep["f_covptot"]["max_abs_err"] == 0.0 and rep["f_covptot"]["ok"]
     for d in (ctx["tends"], ctx["diags"]):
         for k, v in d.items():
-            assert bool(torch.isfinite(v.data.as_subclass(torch.Tensor)).all()), k
+            t = v.data.as_subclass(torch.Tensor)
+            assert t.is_cuda and bool(torch.isfinite(t).all()), k
+    ext = default_externals()
+    dg = {k: v.data.as_subclass(torch.Tensor) for k, v in ctx["diags"].items()}
+    assert torch.equal(dg["f_fhpsn"], -dg["f_fplsn"] * ext["RLSTT"])
+    assert torch.equal(dg["f_fhpsl"], -dg["f_fplsl"] * ext["RLVTT"])
+    assert float(dg["f_fplsn"].max()) > 0 and float(dg["f_fplsl"].max()) > 0      # a real signal on both fluxes
+    # the golden fields are tiled to the run's columns like any input (100-column file): column j == column j + 100
+    ref = ctx["diags_ref"]["f_fplsn"].data.as_subclass(torch.Tensor)
+    assert ref.is_cuda and torch.equal(ref[:100], ref[100:200])
 
 
 @pytest.mark.gpu
 def test_config3_taylor_test_65536(gpu, capsys):
-    """run_taylor_test protocol at 65 536 columns: (a) the reader path - 100-column stand-in dataset tiled to
-    65 536 like the reference tiles its 100-column input.h5; (b) 65 536 DISTINCT mixed-regime columns, where a
-    discontinuous scheme always has a few of its 9 million points sitting on a branch threshold: the V shape
-    then only emerges once factor2 is small enough that no point flips (norm -> 1 to 1e-6 or better)."""
+    """run_taylor_test protocol at 65 536 columns.  (a) The reader path - the 100-column stand-in dataset tiled to
+    65 536 like the reference tiles its 100-column input.h5 - must earn the reference's own verdict, "The test passed
+    with penalty ..." (tangent_linear/validation.py:183-217).  (b) 65 536 DISTINCT mixed-regime columns: a
+    discontinuous scheme always has a few of its 9 million points sitting on a branch threshold, so the reference's
+    scoring rule may say "failed with error 10" there (non-monotone head) although the norm still converges to 1 to
+    1e-6 - whatever it says, the oracle must say the same on the same columns (next test)."""
     from gt4py_dwarf_p_cloudsc2_tl_ad_amd.drivers import run_taylor_test
 
     ctx = run_taylor_test.main(["--backend", "hip", "--num-cols", "65536", "--num-runs", "2"])
     out = capsys.readouterr().out
+    print(out)
     err = np.abs(1 - ctx["norms"])
     assert ">>> Taylor test: Start" in out and "<<< Taylor test: End" in out
+    assert ctx["passed"] is True and "The test passed with penalty" in out, out
     assert err.min() < 1e-6 and np.all(np.diff(err[:6]) < 0), ctx["norms"]
-    print(out)
     ctx = run_taylor_test.main(["--backend", "hip", "--num-cols", "65536", "--num-runs", "1", "--input", "synthetic"])
-    print(capsys.readouterr().out)
+    out = capsys.readouterr().out
+    print(out)
     assert np.abs(1 - ctx["norms"]).min() < 1e-6, ctx["norms"]
+    assert ("The test passed with penalty" in out) == bool(ctx["passed"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("source", ["auto", "synthetic"])
+def test_taylor_verdict_on_hip_equals_the_oracles(gpu, capsys, oracle_numpy_backend, source):
+    """The reference's Taylor verdict, HIP kernels vs the oracle on the SAME columns (2 048: a size the NumPy oracle
+    follows in seconds): same verdict string, same norms down to the round-off regime."""
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.drivers import run_taylor_test
+
+    args = ["--num-cols", "2048", "--num-runs", "1", "--input", source]
+    hip = run_taylor_test.main(["--backend", "hip"] + args)
+    out_hip = capsys.readouterr().out
+    ref = run_taylor_test.main(["--backend", "numpy"] + args)
+    out_ref = capsys.readouterr().out
+    verdict = lambda o: [l for l in o.splitlines() if l.startswith("The test ")]  # noqa: E731
+    assert verdict(out_hip) == verdict(out_ref) and len(verdict(out_hip)) == 1, (verdict(out_hip), verdict(out_ref))
+    assert hip["passed"] == ref["passed"]
+    if source == "auto":
+        assert hip["passed"] is True and "The test passed with penalty" in out_hip
+    # the first norms agree to ~1e-8 (different exp / reciprocals); deep in the round-off regime only the error level
+    np.testing.assert_allclose(hip["norms"][:6], ref["norms"][:6], rtol=1e-6)
+    eh, er = np.abs(1 - hip["norms"]), np.abs(1 - ref["norms"])
+    assert abs(np.log10(eh.min()) - np.log10(er.min())) < 1.5
+    print(out_hip)
 
 
 @pytest.mark.gpu
@@ -127,8 +181,13 @@ def test_config4_symmetry_test_65536(gpu, capsys):
     assert ctx["passed"], ctx["detail"]                      # 65 536 distinct mixed-regime columns, consistent AD
     ctx = run_symmetry_test.main(["--backend", "hip", "--num-cols", "65536", "--num-runs", "1", "--input", "synthetic"])
     d = ctx["detail"]
-    assert d["columns_passing"] / d["columns"] > 0.95, d     # reference-literal AD: only RTT-crossing columns fail
-    print(capsys.readouterr().out)
+    # reference-literal AD on DISTINCT mixed-regime columns: the columns whose saturation adjustment crosses RTT fail
+    # (quirks Q4/Q5 - a property of the reference, reproduced by the oracle too), so the reference's verdict here is
+    # "failed" and only > 95 % of the columns pass
+    assert d["columns_passing"] / d["columns"] > 0.95, d
+    out = capsys.readouterr().out
+    assert ("The symmetry test failed." in out) == (not ctx["passed"])
+    print(out)
 
 
 @pytest.mark.gpu
@@ -221,4 +280,36 @@ def test_nonlinear_driver_with_hip_graph(gpu, capsys):
         for d in ("tends", "diags"):
             for k, v in a[d].items():
                 assert torch.equal(v.data, b[d][k].data), (extra, k)
+    capsys.readouterr()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["double", "single"])
+def test_eta_levels_on_the_device_match_the_oracle(gpu, precision, capsys):
+    """`EtaLevels` (common/diagnostics.py:42-45) as the drivers run it on HIP storages: f_eta[k] =
+    ap[column 0, k] / aph[column 0, nz], one device slice operation - bit-equal to the oracle's level loop and to the
+    host-side `synthetic.eta_levels` the sharded runs use (global column 0)."""
+    import argparse
+
+    import torch
+
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd import storage
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.drivers._common import add_common_options, setup
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.synthetic import eta_levels
+    from oracle import cloudsc2_numpy as oracle
+
+    ap = argparse.ArgumentParser()
+    add_common_options(ap)
+    for source in ("synthetic", "auto"):
+        args = ap.parse_args(["--backend", "hip", "--num-cols", "333", "--precision", precision, "--input", source])
+        ctx = setup(args)
+        st = ctx["state"]
+        eta = st["f_eta"].data.as_subclass(torch.Tensor)
+        assert eta.is_cuda and eta.shape == (138,)
+        want = oracle.eta_levels(storage.klayout(st["f_ap"].data).cpu().numpy(), storage.klayout(st["f_aph"].data).cpu().numpy())
+        assert want.dtype == (np.float64 if precision == "double" else np.float32)
+        assert np.array_equal(eta.cpu().numpy(), want), source
+        assert 0.0 < want[0] < 1e-3 and 0.99 < want[136] < 1.0 and want[137] == 0.0 and np.all(np.diff(want[:137]) > 0)
+        if source == "synthetic":
+            assert np.array_equal(want, eta_levels(137, dtype=want.dtype))
     capsys.readouterr()

@@ -135,3 +135,69 @@ def test_stencil_call_signature_errors(hip_lib):
     with pytest.raises(TypeError, match="'f'"):
         inc(**{"in_" + n: z() for n in INC}, **{"out_" + n + "_i": z() for n in INC}, origin=(0, 0, 0),
             domain=(nx, 1, nz + 1), validate_args=True, exec_info=None)
+
+
+def test_outputs_must_not_alias_other_fields(hip_lib):
+    """Debug check of validate_args=True (SURVEY.md 5 "race detection"): an output that shares storage with another
+    field of the same call is refused before anything is launched; column windows of ONE allocation that merely
+    interleave (lev_stride > nx) are legal."""
+    import torch
+
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd import storage
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.stencils import NL_IN, NL_OUT, _windows_overlap, compile_stencil
+
+    # the window arithmetic: nx = 4 columns, 3 levels, level stride 10 elements of 8 bytes
+    assert _windows_overlap(1000, 1000, 8, 4, 3, 10)
+    assert _windows_overlap(1000, 1000 + 3 * 8, 8, 4, 3, 10)              # columns [0,4) and [3,7): share column 3
+    assert not _windows_overlap(1000, 1000 + 4 * 8, 8, 4, 3, 10)          # columns [0,4) and [4,8): disjoint windows
+    assert not _windows_overlap(1000 + 4 * 8, 1000, 8, 4, 3, 10)
+    assert _windows_overlap(1000, 1000 + 10 * 8, 8, 4, 3, 10)             # shifted by one level: levels 1,2 shared
+    assert not _windows_overlap(1000, 1000 + 30 * 8, 8, 4, 3, 10)         # shifted by all 3 levels: disjoint
+    assert _windows_overlap(1000, 1000 + 4, 8, 4, 3, 10)                  # misaligned pair: byte ranges decide
+    nx, nz = 8, 4
+    z = lambda: storage.zeros(nx, nz, torch.float64, "cpu")  # noqa: E731
+    nl = compile_stencil("cloudsc2_nl", {"NLEV": nz})
+    good = {**{"in_" + n: z() for n in NL_IN}, **{"out_" + n: z() for n in NL_OUT}}
+    nl._check_disjoint(good, nx, nz + 1, nx, 8)                           # distinct storages pass
+    with pytest.raises(ValueError, match="out_tnd_t.*overlaps.*in_t"):
+        nl._check_disjoint({**good, "out_tnd_t": good["in_t"]}, nx, nz + 1, nx, 8)            # in-place update
+    with pytest.raises(ValueError, match="overlaps"):
+        nl._check_disjoint({**good, "out_clc": good["out_covptot"]}, nx, nz + 1, nx, 8)       # two outputs, one buffer
+    # two windows of one allocation: columns [0, 8) and [8, 16) with lev_stride 16 interleave but never touch
+    big = torch.zeros((nz + 1, 2 * nx), dtype=torch.float64)
+    wa, wb = storage.logical_view(big[:, :nx]), storage.logical_view(big[:, nx:])
+    nl._check_disjoint({**good, "in_t": wa, "out_tnd_t": wb}, nx, nz + 1, 2 * nx, 8)
+    ad = compile_stencil("cloudsc2_ad", {"NLEV": nz})
+    ad_fields = {**{"in_" + n: z() for n in NL_IN}, **{"in_" + n + "_i": z() for n in NL_OUT},
+                 **{"out_" + n: z() for n in NL_OUT}, **{"out_" + n + "_i": z() for n in NL_IN}}
+    ad._check_disjoint(ad_fields, nx, nz + 1, nx, 8)
+    with pytest.raises(ValueError, match="out_tnd_t'? overlaps"):                              # AD re-reads its forcing
+        ad._check_disjoint({**ad_fields, "out_tnd_t": ad_fields["in_tnd_t_i"]}, nx, nz + 1, nx, 8)
+
+
+def test_nlev_external_must_match_the_storages(hip_lib):
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.stencils import compile_stencil
+
+    tl = compile_stencil("cloudsc2_tl", {"NLEV": 137})
+    tl._validate = True
+    tl._set_nlev(137)
+    with pytest.raises(ValueError, match="NLEV=137 does not match"):
+        tl._set_nlev(90)
+    tl._validate = False            # validate_args=False: the storages decide (the kernels' bounds depend on it)
+    tl._set_nlev(90)
+    assert tl.params.NLEV == 90
+    ad = compile_stencil("cloudsc2_ad", {})     # no NLEV given: derived from the storages
+    ad._validate = True
+    ad._set_nlev(60)
+    assert ad.params.NLEV == 60
+
+
+def test_level_limit_is_an_argument_error_not_a_launch_failure(hip_lib):
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd import _lib
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.params import default_externals, make_params
+
+    p = make_params(dict(default_externals(), NLEV=4096))
+    ins, outs = _lib.ptr_array([4096] * 16), _lib.ptr_array([4096] * 10)
+    assert hip_lib.cloudsc2_nl_f64(ctypes.byref(p), 64, 4096, 64, ins, 4096, outs, 3600.0, None) == -1
+    assert "nz=4096" in _lib.last_error()
+    assert isinstance(_lib.last_kernel(), str)   # diagnostics entry point answers without a launch ("" then)

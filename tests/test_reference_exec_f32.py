@@ -32,9 +32,10 @@ INC = ("aph", "ap", "q", "qsat", "t", "ql", "qi", "lude", "lu", "mfu", "mfd",
 # HIP fp32 vs executed-reference fp32, as a fraction of each COLUMN's own scale (max |want| over the column's levels).
 # Both sides round every operation to float32 but associate differently (shared reciprocals, fused multiply-adds, a
 # different exp): measured on the GPU (profiles/r02/fp32_errors.txt) and set ~4x above the worst case seen.
-HIP_NL_TOL = 2e-5          # NL outputs and the NL trajectory recomputed by TL / AD
-HIP_TL_TOL = 2e-4          # TL perturbation outputs
-HIP_AD_TOL = 1e-3          # adjoint outputs (differences of nearly equal numbers)
+HIP_NL_TOL = 3e-5          # NL outputs and the NL trajectory recomputed by TL / AD, driver switches (measured <= 6.4e-6)
+HIP_NL_EVAP_TOL = 4e-4     # the same with the evaporation block (measured <= 8.8e-5: nearly evaporated rain fluxes)
+HIP_TL_TOL = 1e-4          # TL perturbation outputs (measured <= 1.8e-5)
+HIP_AD_TOL = 1e-4          # adjoint outputs (measured <= 1.6e-5); out_lu_i apart, see test_oracle_f32_ad
 
 
 @pytest.fixture(scope="module")
@@ -152,7 +153,7 @@ def test_hip_f32_nl_matches_reference_source(gpu, gold32, tag, flags):
     got = run_hip_nl(fields, eta, dt, externals(**flags), gpu, fields["in_ap"].shape[1], NZ)
     for n in NL_OUT:
         k = nlev_of(n, NZ)
-        close_by_column(f"{tag} out_{n}", got[n][:k], g[f"{tag}_out_{n}"][:k], HIP_NL_TOL)
+        close_by_column(f"{tag} out_{n}", got[n][:k], g[f"{tag}_out_{n}"][:k], HIP_NL_EVAP_TOL if flags else HIP_NL_TOL)
 
 
 @pytest.mark.gpu
@@ -168,7 +169,7 @@ def test_hip_f32_tl_matches_reference_source(gpu, gold32, tag, flags, inc, dt60)
                             fields["in_ap"].shape[1], NZ)
     for n in NL_OUT:
         k = nlev_of(n, NZ)
-        close_by_column(f"{tag} out_{n}", got[n][:k], g[f"{tag}_out_{n}"][:k], HIP_NL_TOL)
+        close_by_column(f"{tag} out_{n}", got[n][:k], g[f"{tag}_out_{n}"][:k], HIP_NL_EVAP_TOL if dt60 else HIP_NL_TOL)
         close_by_column(f"{tag} out_{n}_i", got_i[n][:k], g[f"{tag}_out_{n}_i"][:k], HIP_TL_TOL)
 
 
@@ -184,10 +185,11 @@ def test_hip_f32_ad_matches_reference_source(gpu, gold32, tag, flags, tl_tag, dt
                             fields["in_ap"].shape[1], NZ)
     for n in NL_OUT:
         k = nlev_of(n, NZ)
-        close_by_column(f"{tag} out_{n}", got[n][:k], g[f"{tag}_out_{n}"][:k], HIP_NL_TOL)
+        close_by_column(f"{tag} out_{n}", got[n][:k], g[f"{tag}_out_{n}"][:k], HIP_NL_EVAP_TOL if dt60 else HIP_NL_TOL)
     for n in NL_IN:
         k = 138 if n in ("aph", "lu") else 137
-        if n == "lu":      # see test_oracle_f32_ad
-            close_by_column(f"{tag} out_{n}_i", got_i[n][:k], g[f"{tag}_out_{n}_i"][:k], 5e-3, whole_field=True)
+        if n == "lu":      # see test_oracle_f32_ad (measured: 2.7e-3 of the field scale with evaporation, 2.5e-5 without)
+            close_by_column(f"{tag} out_{n}_i", got_i[n][:k], g[f"{tag}_out_{n}_i"][:k], 1e-2 if dt60 else 1e-4,
+                            whole_field=True)
         else:
             close_by_column(f"{tag} out_{n}_i", got_i[n][:k], g[f"{tag}_out_{n}_i"][:k], HIP_AD_TOL)

@@ -29,6 +29,10 @@
 // parks it in level k of out_mfd_i, sweep 2 reads it back before it overwrites that element.
 #include "cloudsc2_common.hpp"
 
+#ifndef CS2_AD_DIAG
+#define CS2_AD_DIAG 0   // diagnostics only (wrong results): 1 = the kernel's memory traffic without the physics
+#endif
+
 namespace cs2 {
 
 template <typename T>
@@ -173,6 +177,15 @@ template <typename T, bool FIX, bool EVAP>
 __device__ __forceinline__ void ad_forward(const Ext<T>& e, const NLK<T>& kc, const ExpK<T>& xk, const ADIn<T>& x,
                                            T aph_k, int k, T eta_k, T scalm, const CrhCol<T>& crh, T dt, T rfl, T sfl,
                                            T covptot_in, T aph_s, ADTraj<T>& r) {
+#if CS2_AD_DIAG == 1
+    {
+        const T s1 = x.ap + x.aph1 + x.lu1 + x.lude + x.mfd + x.mfu + x.q + x.qi + x.ql + x.qsat + x.supsat + x.t + x.tq + x.tqi +
+                     x.tql + x.tt + aph_k;
+        r.out_clc = s1; r.out_covptot = s1 + T(1); r.tnd_q = s1 + T(2); r.tnd_t = s1 + T(3); r.tnd_ql = s1 + T(4); r.tnd_qi = s1 + T(5);
+        r.rfln = rfl + s1; r.sfln = sfl + s1; r.covptot = covptot_in; r.t2 = s1;
+        return;
+    }
+#endif
     // :135-137, :153-157
     T t = x.t + dt * x.tt;
     r.t2 = t;
@@ -460,6 +473,15 @@ template <typename T, bool REG, bool FIX, bool EVAP>
 __device__ __forceinline__ ADOut<T> ad_backward(const Ext<T>& e, const NLK<T>& kc, const ADIn<T>& x, int k, T scalm,
                                                 T dt, T sfl, const ADTraj<T>& r, const ADForce<T>& f, ADBack<T>& b) {
     ADOut<T> o;
+#if CS2_AD_DIAG == 1
+    {
+        const T s2 = f.clc + f.tnd_q + f.tnd_qi + f.tnd_ql + f.tnd_t + f.fplsl1 + f.fplsn1 + r.t2 + sfl + b.tmp_rfln_i;
+        o.ap = s2; o.t = s2 + T(1); o.q = s2 + T(2); o.ql = s2 + T(3); o.qi = s2 + T(4); o.qsat = s2 + T(5); o.lude = s2 + T(6);
+        o.mfd = s2 + T(7); o.mfu = s2 + T(8); o.aph1 = s2 + T(9); o.lu1 = s2 + T(10);
+        b.tmp_rfln_i = s2;
+        return o;
+    }
+#endif
     const T ckcodtla = kc.ckcodtl * T(0.01);
     const T ckcodtia = kc.ckcodti * T(0.01);
     const T cons2 = kc.cons2, rdt = kc.rdt;

@@ -11,6 +11,10 @@
 // autoconversion thresholds; never enabled by the reference's own drivers).
 #include "cloudsc2_common.hpp"
 
+#ifndef CS2_TL_DIAG
+#define CS2_TL_DIAG 0   // diagnostics only (wrong results): 1 = the kernel's memory traffic without the physics
+#endif
+
 namespace cs2 {
 
 template <typename T>
@@ -92,6 +96,20 @@ __device__ __forceinline__ TLOut<T> tl_level(const Ext<T>& e, const NLK<T>& kc, 
                                              const TLIn<T>& y, int k, T eta_k, T scalm, const CrhCol<T>& crh, T dt,
                                              TLCarry<T>& c) {
     TLOut<T> o;
+#if CS2_TL_DIAG == 1
+    {
+        const T s1 = x.ap + x.aph1 + x.lu1 + x.lude + x.mfd + x.mfu + x.q + x.qi + x.ql + x.qsat + x.supsat + x.t + x.tq + x.tqi +
+                     x.tql + x.tt;
+        const T s2 = y.ap + y.aph1 + y.lu1 + y.lude + y.mfd + y.mfu + y.q + y.qi + y.ql + y.qsat + y.supsat + y.t + y.tq + y.tqi +
+                     y.tql + y.tt;
+        o.clc = s1; o.clc_i = s2; o.tnd_q = s1 + s2; o.tnd_q_i = s1 - s2; o.tnd_t = s1 * s2; o.tnd_t_i = s2 - s1;
+        o.tnd_ql = s1 + T(1); o.tnd_ql_i = s2 + T(1); o.tnd_qi = s1 + T(2); o.tnd_qi_i = s2 + T(2);
+        o.rfln = c.rfl + s1; o.rfln_i = c.rfl_i + s2; o.sfln = c.sfl + s2; o.sfln_i = c.sfl_i + s1;
+        o.covptot = s1 - T(1); o.covptot_i = s2 - T(1);
+        c.rfl = o.rfln; c.rfl_i = o.rfln_i; c.sfl = o.sfln; c.sfl_i = o.sfln_i; c.aph_k = x.aph1; c.aph_k_i = y.aph1;
+        return o;
+    }
+#endif
     // :139-140, :151-156
     T t = x.t + dt * x.tt;
     T t_i = y.t + dt * y.tt;
@@ -591,6 +609,231 @@ tl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// LDS-ring variant of the sweep.  Same prologue, same tl_level / tl_store; only the way the 32 input words of a level
+// (16 trajectory + 16 perturbation fields) reach the lane differs - the load path of cloudsc2_nl.hip's nl_ring_kernel,
+// restated for 32 fields:
+//   * every wave owns RD slots of 32 fields x 64 columns in LDS (16 KB per slot in fp64); level k + RD - 1 is requested
+//     with LDS-DMA (`global_load_lds_dwordx4`, no VGPR destination) while level k is computed.  In fp64 RD = 2 is what
+//     fits a CU (4 waves x 2 x 16 KB + table): the same one level ahead as the register prefetch of tl_kernel, but
+//     without its 32-double landing buffer (64 VGPRs) - the register path runs at 254-256 VGPRs + 36-96 AGPRs;
+//   * one DMA instruction moves 16 B per lane = NPL columns (2 fp64 / 4 fp32): lane group g of instruction i fetches
+//     field i*NPL + g of the concatenated list [in[0..15], in_i[0..15]], so field f of a slot starts at
+//     f * 64 * sizeof(T) and the lane reads its own column with ds_read_b64 / _b32;
+//   * the waits are counted by hand (vmcnt retires in order on gfx9): when level k is read, the operations younger than
+//     its DMAs are the (RD-1) x NI DMAs of the levels in flight and the (RD-1) x 20 stores of the levels computed since.
+//     Unlike nl_ring_kernel (three slots, one level of stores of slack) the count is EXACT here: with two slots a
+//     stricter wait would expose the completion latency of the previous level's stores on every level.  tl_store
+//     issues exactly kTLStores stores per level (20 distinct fields; profiles/check_ring_counts.py counts them in the ISA).
+// Used when the launcher can guarantee 16-byte aligned rows and whole waves (launch_tl); every other call takes the
+// register-prefetch kernel above.  Results are bit-identical (same arithmetic on the same words).
+#ifndef CS2_TL_RING
+#define CS2_TL_RING 2   // slots per wave in fp64 (0 disables the variant)
+#endif
+#ifndef CS2_TL_RING_F32
+#define CS2_TL_RING_F32 2
+#endif
+#ifndef CS2_TL_RING_AUX
+#define CS2_TL_RING_AUX (CS2_NT & 1 ? 2 : 0)   // cache policy of the input DMAs: 2 = nt (every byte is read once)
+#endif
+typedef __attribute__((address_space(3))) void* tl_lds_ptr;
+typedef const __attribute__((address_space(1))) void* tl_glb_ptr;
+constexpr int kTLFields = 2 * NL_NUM_IN;    // input words per level and column
+constexpr int kTLStores = 2 * NL_NUM_OUT;   // stores per level (tl_store)
+
+template <typename T>
+struct TLRingGeom {
+    static constexpr int NPL = 16 / int(sizeof(T));             // columns per lane per DMA = fields per DMA
+    static constexpr int NI = kTLFields / NPL;                   // DMA instructions per level
+    static constexpr int SLOT = kTLFields * 64 * int(sizeof(T));  // the 32 input fields of one level
+};
+
+// Wait until at most N vector-memory operations are outstanding, then read this lane's column of 16 fields of the slot
+// at LDS byte address `a` (+ table entries eta[k] at `ta`, scalm[k] at `tb` when TAB).  Two statements per level (x, y):
+// the wait and the LDS reads live in ONE asm statement with a memory clobber - hipcc would otherwise drain vmcnt(0)
+// before every LDS read that follows an LDS-DMA, and no store may move across the wait.
+template <int N>
+__device__ __forceinline__ void tl_ring_read16(uint32_t a, TLIn<double>& x) {
+    asm volatile(
+        "s_waitcnt vmcnt(%17)\n\t"
+            "ds_read_b64 %0, %16\n\t"
+            "ds_read_b64 %1, %16 offset:512\n\t"
+            "ds_read_b64 %2, %16 offset:1024\n\t"
+            "ds_read_b64 %3, %16 offset:1536\n\t"
+            "ds_read_b64 %4, %16 offset:2048\n\t"
+            "ds_read_b64 %5, %16 offset:2560\n\t"
+            "ds_read_b64 %6, %16 offset:3072\n\t"
+            "ds_read_b64 %7, %16 offset:3584\n\t"
+            "ds_read_b64 %8, %16 offset:4096\n\t"
+            "ds_read_b64 %9, %16 offset:4608\n\t"
+            "ds_read_b64 %10, %16 offset:5120\n\t"
+            "ds_read_b64 %11, %16 offset:5632\n\t"
+            "ds_read_b64 %12, %16 offset:6144\n\t"
+            "ds_read_b64 %13, %16 offset:6656\n\t"
+            "ds_read_b64 %14, %16 offset:7168\n\t"
+            "ds_read_b64 %15, %16 offset:7680\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(x.ap), "=&v"(x.aph1), "=&v"(x.lu1), "=&v"(x.lude), "=&v"(x.mfd), "=&v"(x.mfu), "=&v"(x.q), "=&v"(x.qi),
+          "=&v"(x.ql), "=&v"(x.qsat), "=&v"(x.supsat), "=&v"(x.t), "=&v"(x.tq), "=&v"(x.tqi), "=&v"(x.tql), "=&v"(x.tt)
+        : "v"(a), "n"(N)
+        : "memory");
+}
+template <int N>
+__device__ __forceinline__ void tl_ring_read16(uint32_t a, TLIn<float>& x) {
+    asm volatile(
+        "s_waitcnt vmcnt(%17)\n\t"
+            "ds_read_b32 %0, %16\n\t"
+            "ds_read_b32 %1, %16 offset:256\n\t"
+            "ds_read_b32 %2, %16 offset:512\n\t"
+            "ds_read_b32 %3, %16 offset:768\n\t"
+            "ds_read_b32 %4, %16 offset:1024\n\t"
+            "ds_read_b32 %5, %16 offset:1280\n\t"
+            "ds_read_b32 %6, %16 offset:1536\n\t"
+            "ds_read_b32 %7, %16 offset:1792\n\t"
+            "ds_read_b32 %8, %16 offset:2048\n\t"
+            "ds_read_b32 %9, %16 offset:2304\n\t"
+            "ds_read_b32 %10, %16 offset:2560\n\t"
+            "ds_read_b32 %11, %16 offset:2816\n\t"
+            "ds_read_b32 %12, %16 offset:3072\n\t"
+            "ds_read_b32 %13, %16 offset:3328\n\t"
+            "ds_read_b32 %14, %16 offset:3584\n\t"
+            "ds_read_b32 %15, %16 offset:3840\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(x.ap), "=&v"(x.aph1), "=&v"(x.lu1), "=&v"(x.lude), "=&v"(x.mfd), "=&v"(x.mfu), "=&v"(x.q), "=&v"(x.qi),
+          "=&v"(x.ql), "=&v"(x.qsat), "=&v"(x.supsat), "=&v"(x.t), "=&v"(x.tq), "=&v"(x.tqi), "=&v"(x.tql), "=&v"(x.tt)
+        : "v"(a), "n"(N)
+        : "memory");
+}
+// eta[k] (LDS byte address ta) and scalm[k] (tb) from the level table; the table is written before the only workgroup
+// barrier and never again, so no vector-memory wait is involved
+__device__ __forceinline__ void tl_table_read(uint32_t ta, uint32_t tb, double& eta_k, double& scalm_k) {
+    asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(eta_k), "=&v"(scalm_k) : "v"(ta), "v"(tb) : "memory");
+}
+__device__ __forceinline__ void tl_table_read(uint32_t ta, uint32_t tb, float& eta_k, float& scalm_k) {
+    asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(eta_k), "=&v"(scalm_k) : "v"(ta), "v"(tb) : "memory");
+}
+
+template <typename T, bool REG, bool EVAP, int RD>
+__global__ void __launch_bounds__(kColBlock, 1)
+tl_ring_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, NL_NUM_IN> in,
+               CPtrs<T, NL_NUM_IN> in_i, const T* __restrict__ eta, MPtrs<T, NL_NUM_OUT> out, MPtrs<T, NL_NUM_OUT> out_i,
+               T dt) {
+    using G = TLRingGeom<T>;
+    static_assert(kColBlock % 64 == 0 && RD >= 2, "whole waves, at least one level in flight");
+    static_assert((RD - 1) * (G::NI + kTLStores) < 64, "vmcnt is a 6-bit counter");
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    T* s_eta = reinterpret_cast<T*>(smem_raw);
+    T* s_scalm = s_eta + (nz + 1);
+    int klo, khi;
+    build_level_table<T>(eta, nz, e, s_eta, s_scalm, klo, khi);
+    if constexpr (sizeof(T) == 8) {
+        pin_vgpr(e.RCPD); pin_vgpr(e.RLSTT); pin_vgpr(e.RLVTT); pin_vgpr(e.RLMLT); pin_vgpr(e.R4LES);
+        pin_vgpr(e.R4IES); pin_vgpr(e.RTT); pin_vgpr(e.R3IES); pin_vgpr(e.R3LES); pin_vgpr(e.R2ES);
+        pin_vgpr(e.ZQMAX); pin_vgpr(e.RETV); pin_vgpr(e.R5LES); pin_vgpr(e.R5IES); pin_vgpr(e.RG);
+        pin_vgpr(e.RD); pin_vgpr(kc.rdt); pin_vgpr(kc.cons2); pin_vgpr(kc.rRD); pin_vgpr(kc.rRCPD); pin_vgpr(dt);
+        pin_vgpr(xk.l2e); pin_vgpr(xk.ln2h); pin_vgpr(xk.ln2l); pin_vgpr(xk.c12); pin_vgpr(xk.c11);
+        pin_vgpr(xk.c10); pin_vgpr(xk.c9); pin_vgpr(xk.c8); pin_vgpr(xk.c7); pin_vgpr(xk.c6);
+        pin_vgpr(xk.c5); pin_vgpr(xk.c4); pin_vgpr(xk.c3);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wcol0 = blockIdx.x * kColBlock + wave * 64;   // first column of this wave
+    if (wcol0 >= nx) return;                                // nx % 64 == 0 (launcher): whole waves retire; the only
+                                                            // workgroup barrier is inside build_level_table
+    const uint32_t lsb = uint32_t(ls) * uint32_t(sizeof(T));
+    const uint32_t colb = uint32_t(wcol0 + lane) * uint32_t(sizeof(T));
+
+    const T trpaus = trpaus_prescan<T>(in.p[NL_IN_T], in.p[NL_IN_TND_CML_T], lsb, colb, dt, s_eta, klo, khi);
+    const CrhCol<T> crh = crh_setup<T>(trpaus);
+
+    // :124-135
+    TLCarry<T> c;
+    c.rfl = c.rfl_i = c.sfl = c.sfl_i = c.covptot = c.covptot_i = T(0.0);
+    c.aph_k = ldg(in.p[NL_IN_APH], colb);
+    c.aph_k_i = ldg(in_i.p[NL_IN_APH], colb);
+    c.aph_s = EVAP ? ldg(in.p[NL_IN_APH], uint32_t(nz) * lsb + colb) : T(1.0);
+    c.aph_s_i = EVAP ? ldg(in_i.p[NL_IN_APH], uint32_t(nz) * lsb + colb) : T(0.0);
+    // :757-765
+    stg(out.p[NL_OUT_FPLSL], colb, T(0.0));
+    stg(out_i.p[NL_OUT_FPLSL], colb, T(0.0));
+    stg(out.p[NL_OUT_FPLSN], colb, T(0.0));
+    stg(out_i.p[NL_OUT_FPLSN], colb, T(0.0));
+    stg(out.p[NL_OUT_FHPSL], colb, T(0.0));
+    stg(out_i.p[NL_OUT_FHPSL], colb, T(0.0));
+    stg(out.p[NL_OUT_FHPSN], colb, T(0.0));
+    stg(out_i.p[NL_OUT_FHPSN], colb, T(0.0));
+    // consume the prologue's ordinary loads BEFORE the first DMA is issued: hipcc drains vmcnt(0) at the first use of
+    // an ordinary load's result while an LDS-DMA is in flight, which would empty the ring inside level 0
+    pin_vgpr(c.aph_k);
+    pin_vgpr(c.aph_k_i);
+    if constexpr (EVAP) { pin_vgpr(c.aph_s); pin_vgpr(c.aph_s_i); }
+    { T tp = crh.rh2; pin_vgpr(tp); }
+
+    // per-lane DMA sources: lane group g of instruction i walks field i*NPL + g of [in | in_i], NPL adjacent columns
+    // per lane; aph and lu are read one half level below (aph[k+1], lu[k+1]: :171, :311)
+    constexpr int LPG = 64 / G::NPL;   // lanes per group
+    const int g = lane / LPG, l = lane % LPG;
+    const char* src[G::NI];
+#pragma unroll
+    for (int i = 0; i < G::NI; ++i) {
+        const int f0 = i * G::NPL;                       // first field of this instruction (compile-time)
+        const T* base = f0 < NL_NUM_IN ? in.p[f0] : in_i.p[f0 - NL_NUM_IN];
+        int f = f0;
+#pragma unroll
+        for (int j = 1; j < G::NPL; ++j)
+            if (g == j) {
+                base = (f0 + j) < NL_NUM_IN ? in.p[f0 + j] : in_i.p[f0 + j - NL_NUM_IN];
+                f = f0 + j;
+            }
+        const int fn = f % NL_NUM_IN;
+        const uint32_t lev1 = (fn == NL_IN_APH || fn == NL_IN_LU) ? lsb : 0u;
+        src[i] = reinterpret_cast<const char*>(base) + (uint32_t(wcol0 + G::NPL * l) * uint32_t(sizeof(T)) + lev1);
+    }
+    // LDS: [eta | scalm table][pad][wave 0: RD slots][wave 1: RD slots] ...
+    const uint32_t tab_bytes = (2u * uint32_t(nz + 1) * uint32_t(sizeof(T)) + 1023u) & ~1023u;
+    const uint32_t ring0 = tab_bytes + uint32_t(wave) * uint32_t(RD * G::SLOT);
+    auto issue = [&](int slot) {
+#pragma unroll
+        for (int i = 0; i < G::NI; ++i) {
+            __builtin_amdgcn_global_load_lds((tl_glb_ptr)src[i],
+                                             (tl_lds_ptr)(&smem_raw[ring0 + uint32_t(slot * G::SLOT + i * 1024)]), 16, 0,
+                                             CS2_TL_RING_AUX);
+            src[i] += lsb;
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < RD - 1; ++j)
+        if (j < nz) issue(j);
+
+    // operations younger than level k's DMAs when level k is read: see the header of this kernel
+    constexpr int NFULL = (RD - 1) * (G::NI + kTLStores);
+    constexpr int NHEAD = (RD - 1) * G::NI;   // the first RD-1 levels: no stores counted (stricter = safe)
+    const uint32_t rd_lane = ring0 + uint32_t(lane) * uint32_t(sizeof(T));
+    const uint32_t tb_off = uint32_t(nz + 1) * uint32_t(sizeof(T));
+    constexpr uint32_t YOFF = uint32_t(NL_NUM_IN) * 64u * uint32_t(sizeof(T));   // the perturbation half of a slot
+    uint32_t o = colb;
+    int slot = 0, pslot = RD - 1;
+    for (int k = 0; k < nz; ++k) {
+        const bool more = k + RD - 1 < nz;
+        if (more) issue(pslot);
+        TLIn<T> x, y;
+        T eta_k, scalm_k;
+        const uint32_t a = rd_lane + uint32_t(slot * G::SLOT);
+        const uint32_t ta = uint32_t(k) * uint32_t(sizeof(T));
+        if (!more) tl_ring_read16<0>(a, x);   // tail: drain
+        else if (k < RD - 1) tl_ring_read16<NHEAD>(a, x);
+        else tl_ring_read16<NFULL>(a, x);
+        tl_ring_read16<63>(a + YOFF, y);      // same level, already covered by the wait above (63 = no further wait)
+        tl_table_read(ta, ta + tb_off, eta_k, scalm_k);
+        const TLOut<T> r = tl_level<T, REG, EVAP>(e, kc, xk, x, y, k, eta_k, scalm_k, crh, dt, c);
+        tl_store<T>(out, out_i, e, lsb, o, r);
+        o += lsb;
+        slot = slot + 1 == RD ? 0 : slot + 1;
+        pslot = pslot + 1 == RD ? 0 : pslot + 1;
+    }
+}
+
 template <typename T>
 int launch_tl(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* const* in, const T* const* in_i,
               const T* eta, T* const* out, T* const* out_i, double dt, hipStream_t stream) {
@@ -606,6 +849,59 @@ int launch_tl(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
     const NLK<T> kc = make_nlk<T>(p, dt, evap);
     const ExpK<T> xk = make_expk<T>();
     if (!fits_u32_offsets<T>(nz, ls)) return -2;
+    constexpr int kRing = sizeof(T) == 8 ? CS2_TL_RING : CS2_TL_RING_F32;
+    if constexpr (kRing >= 2) {
+        // LDS-ring variant: whole waves, 16-byte aligned rows of every input field (the DMA moves 16 B per lane)
+        using G = TLRingGeom<T>;
+        bool ring = nx % 64 == 0 && nz >= kRing && (ls * int64_t(sizeof(T))) % 16 == 0;
+        for (int i = 0; i < NL_NUM_IN && ring; ++i)
+            ring = reinterpret_cast<uintptr_t>(in[i]) % 16 == 0 && reinterpret_cast<uintptr_t>(in_i[i]) % 16 == 0;
+        const size_t tab = (2 * size_t(nz + 1) * sizeof(T) + 1023) & ~size_t(1023);
+        const size_t rsmem = tab + size_t(kColBlock / 64) * kRing * G::SLOT;
+        ring = ring && rsmem <= size_t(160) * 1024;   // LDS of a CU; very tall columns take the register path
+        int dev = 0;
+        if (ring && hipGetDevice(&dev) != hipSuccess) return -1;
+        if (ring && sizeof(T) == 8) {
+            // fp64 (two slots per wave = the register path's one level ahead): the ring wins wherever part of the chip is
+            // latency-bound - 8 192 .. 49 152 columns -3.5 .. -6 %, 98 304 (1.5 workgroups per CU) -3.7 % - and loses
+            // 1.5-2 % when every CU holds the same number of workgroups for the whole launch and HBM is saturated
+            // (65 536: 720 vs 710 us, 131 072: 1 518 vs 1 488 us; profiles/r02/ab_tl_ring.txt).  Rule: register path when
+            // at least 3/4 of the launch's workgroup rounds are full.  fp32 (8 KB slots): the ring wins at every size
+            // measured (65 536: 337 vs 389 us; 524 288: 2 986 vs 3 049 us).
+            static int cus[64] = {};
+            if (cus[dev & 63] == 0) {
+                int n = 0;
+                if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+                cus[dev & 63] = n;
+            }
+            const int64_t c = cus[dev & 63], gx = grid.x;
+            const int64_t full = gx / c, rounds = (gx + c - 1) / c;
+            ring = 4 * full < 3 * rounds;
+        }
+        if (ring) {
+#define CS2_TL_RING_LAUNCH(REG, EVAP)                                                                                \
+    do {                                                                                                             \
+        auto kern = tl_ring_kernel<T, REG, EVAP, kRing>;                                                             \
+        /* > 64 KB of dynamic LDS needs the opt-in: once per instantiation, device and size */                       \
+        static size_t attr_set[64] = {};                                                                             \
+        if (attr_set[dev & 63] < rsmem) {                                                                            \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    int(rsmem)) != hipSuccess)                                                       \
+                return -1;                                                                                           \
+            attr_set[dev & 63] = rsmem;                                                                              \
+        }                                                                                                            \
+        hipLaunchKernelGGL(kern, grid, block, rsmem, stream, e, kc, xk, nx, nz, ls, ci, cii, eta, co, coi, tdt);     \
+    } while (0)
+            if (p.LREGCL) {
+                if (evap) CS2_TL_RING_LAUNCH(true, true); else CS2_TL_RING_LAUNCH(true, false);
+            } else {
+                if (evap) CS2_TL_RING_LAUNCH(false, true); else CS2_TL_RING_LAUNCH(false, false);
+            }
+#undef CS2_TL_RING_LAUNCH
+            note_kernel("cs2::tl_ring_kernel");
+            return hipGetLastError() == hipSuccess ? 0 : -1;
+        }
+    }
 #define CS2_TL_LAUNCH(REG, EVAP)                                                                                     \
     hipLaunchKernelGGL((tl_kernel<T, REG, EVAP>), grid, block, smem, stream, e, kc, xk, nx, nz, ls, ci, cii, eta, co, \
                        coi, tdt)

@@ -32,6 +32,28 @@
 #ifndef CS2_AD_DIAG
 #define CS2_AD_DIAG 0   // diagnostics only (wrong results): 1 = the kernel's memory traffic without the physics
 #endif
+// Tuning switches (A/B-tested with profiles/ab_kernels.py; the defaults are the fastest measured set).
+// CS2_AD_PARK: sweep 2 parks the part of a level's recomputed trajectory that the adjoint statements only read in
+// their second half (34 values per column, listed in CS2_AD_PARK_LIST) in LDS between ad_forward and that half, instead
+// of carrying them through the register-pressure peak (cuadj_bwd + the autoconversion adjoint), where hipcc otherwise
+// shuttles them through AGPRs (v_accvgpr_write / _read occupy a VALU issue slot each; ds_write / ds_read do not).
+// Measured (profiles/r02/ab_ad_variants.txt, one process, interleaved): fp64 65 536 columns 922.9 us parked vs 911.7 us
+// not parked - the fp64 kernel runs at 94 % of the time its memory traffic alone takes (CS2_AD_DIAG = 1), so issue slots
+// are not what it waits for; fp32 524 288 columns 3 689 us parked vs 3 817 us (199 -> 166 VGPRs: 3 waves per SIMD
+// instead of 2).  Hence the default: bit 0 = park in the fp64 kernels (off), bit 1 = in the fp32 kernels (on).
+#ifndef CS2_AD_PARK
+#define CS2_AD_PARK 2
+#endif
+template <typename T>
+constexpr bool kADPark = ((CS2_AD_PARK) & (sizeof(T) == 8 ? 1 : 2)) != 0;
+#define CS2_AD_PARK_LIST(X)                                                                                            \
+    X(fac4) X(dqsdz) X(dqc) X(dqsdtemp) X(dtdzmo) X(fac3) X(rodqsdp) X(fac2) X(rho) X(fac1) X(rt) X(clc) X(rlu) X(exlu) \
+    X(lude) X(qt) X(qcrit) X(qsat) X(qpd) X(qcd) X(tmp3) X(rden) X(crh2) X(supsat) X(fac) X(cor) X(facw) X(faci) X(ri)  \
+    X(rl) X(esdp1) X(foeew) X(sech2) X(qc3)
+#define CS2_AD_PARK_COUNT 34
+#ifndef CS2_AD_PIN
+#define CS2_AD_PIN 3    // fp64 constants pinned in VGPRs: bit 0 = the physical constants, bit 1 = the exp coefficients
+#endif
 
 namespace cs2 {
 
@@ -467,11 +489,33 @@ struct ADOut {
     T ap, t, q, ql, qi, qsat, lude, mfd, mfu, aph1, lu1;
 };
 
+// LDS parking of trajectory values across the first half of ad_backward (CS2_AD_PARK): one 8-byte (4-byte) slot per
+// value and lane, [value][lane] - consecutive lanes hit consecutive banks.  The empty asm statements with a memory
+// clobber pin the stores before, and the loads after, everything in between: hipcc may neither forward the stored values
+// in registers nor hoist the loads back up to the stores.
+template <typename T>
+__device__ __forceinline__ void ad_park(T* __restrict__ lds, const ADTraj<T>& r) {
+    int j = 0;
+#define CS2_X(f) lds[(j++) * kColBlock] = r.f;
+    CS2_AD_PARK_LIST(CS2_X)
+#undef CS2_X
+    asm volatile("" ::: "memory");
+}
+template <typename T>
+__device__ __forceinline__ void ad_unpark(const T* __restrict__ lds, ADTraj<T>& r) {
+    asm volatile("" ::: "memory");
+    int j = 0;
+#define CS2_X(f) r.f = lds[(j++) * kColBlock];
+    CS2_AD_PARK_LIST(CS2_X)
+#undef CS2_X
+}
+
 // Backward statements of one level (:494-967 + this level's share of :970-996).  Divisions use the
 // reciprocals saved with the trajectory.
 template <typename T, bool REG, bool FIX, bool EVAP>
 __device__ __forceinline__ ADOut<T> ad_backward(const Ext<T>& e, const NLK<T>& kc, const ADIn<T>& x, int k, T scalm,
-                                                T dt, T sfl, const ADTraj<T>& r, const ADForce<T>& f, ADBack<T>& b) {
+                                                T dt, T sfl, ADTraj<T>& r, const ADForce<T>& f, ADBack<T>& b,
+                                                const T* park_lds = nullptr) {
     ADOut<T> o;
 #if CS2_AD_DIAG == 1
     {
@@ -703,6 +747,7 @@ __device__ __forceinline__ ADOut<T> ad_backward(const Ext<T>& e, const NLK<T>& k
         }
         b.covptot_i = covptot_i;
     }
+    if constexpr (kADPark<T>) ad_unpark<T>(park_lds, r);   // the second half starts here: it reads the parked values
     // :820-825
     qiwc_i += condi_i * rdt;
     o_qi -= condi_i * rdt;
@@ -837,18 +882,23 @@ ad_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
     T* s_scalm = s_eta + (nz + 1);
     int klo, khi;
     build_level_table<T>(eta, nz, e, s_eta, s_scalm, klo, khi);
-    if constexpr (sizeof(T) == 8) {
+    if constexpr (sizeof(T) == 8 && (CS2_AD_PIN & 1)) {
         // fp64 constants of the level loops -> VGPRs (see pin_vgpr in cloudsc2_common.hpp)
         pin_vgpr(e.RCPD); pin_vgpr(e.RLSTT); pin_vgpr(e.RLVTT); pin_vgpr(e.R4LES); pin_vgpr(e.R4IES);
         pin_vgpr(e.RTT); pin_vgpr(e.R3IES); pin_vgpr(e.R3LES); pin_vgpr(e.R2ES); pin_vgpr(e.ZQMAX);
         pin_vgpr(e.RETV); pin_vgpr(e.R5LES); pin_vgpr(e.R5IES); pin_vgpr(e.RG); pin_vgpr(e.RD);
         pin_vgpr(kc.rdt); pin_vgpr(kc.cons2); pin_vgpr(kc.rRD); pin_vgpr(kc.rRCPD); pin_vgpr(dt);
+    }
+    if constexpr (sizeof(T) == 8 && (CS2_AD_PIN & 2)) {
         pin_vgpr(xk.l2e); pin_vgpr(xk.ln2h); pin_vgpr(xk.ln2l); pin_vgpr(xk.c12); pin_vgpr(xk.c11);
         pin_vgpr(xk.c10); pin_vgpr(xk.c9); pin_vgpr(xk.c8); pin_vgpr(xk.c7); pin_vgpr(xk.c6);
         pin_vgpr(xk.c5); pin_vgpr(xk.c4); pin_vgpr(xk.c3);
     }
 
     const int gcol = blockIdx.x * kColBlock + threadIdx.x;
+    // CS2_AD_PARK: this lane's parking slots follow the level table (8-byte aligned)
+    T* const park_lds = s_scalm + (nz + 1) + threadIdx.x;
+    (void)park_lds;
     if (gcol >= nx) return;  // no later workgroup barrier: whole lanes may retire
     const uint32_t lsb = uint32_t(ls) * uint32_t(sizeof(T));
     const uint32_t colb = uint32_t(gcol) * uint32_t(sizeof(T));
@@ -915,6 +965,7 @@ ad_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
             if (k > 0) {
                 const uint32_t om = o - lsb;
                 xn = ad_load<T>(in, lsb, om);
+                xn.aph1 = aph_k;   // aph[k]: already here as this level's upper half level (the load above is dropped)
                 fn = ad_load_force<T, EVAP>(adj, e, lsb, om);
                 aph_n = ldg(in.p[NL_IN_APH], om);
                 sfl_n = ldg(const_cast<const T*>(out.p[NL_OUT_FPLSN]), om);
@@ -923,7 +974,8 @@ ad_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
             }
             ADTraj<T> r;
             ad_forward<T, FIX, EVAP>(e, kc, xk, xa, aph_k, k, s_eta[k], s_scalm[k], crh, dt, rfl, sfl, cov, aph_s, r);
-            const ADOut<T> a = ad_backward<T, REG, FIX, EVAP>(e, kc, xa, k, s_scalm[k], dt, sfl, r, fa, b);
+            if constexpr (kADPark<T>) ad_park<T>(park_lds, r);
+            const ADOut<T> a = ad_backward<T, REG, FIX, EVAP>(e, kc, xa, k, s_scalm[k], dt, sfl, r, fa, b, park_lds);
             stg(oadj.p[NL_IN_AP], o, a.ap);
             stg(oadj.p[NL_IN_T], o, a.t);
             stg(oadj.p[NL_IN_Q], o, a.q);
@@ -970,16 +1022,30 @@ int launch_ad(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
     for (int i = 0; i < NL_NUM_IN; ++i) { ci.p[i] = in[i]; coa.p[i] = out_adj[i]; }
     for (int i = 0; i < NL_NUM_OUT; ++i) { ca.p[i] = in_adj[i]; co.p[i] = out[i]; }
     const dim3 grid((nx + kColBlock - 1) / kColBlock), block(kColBlock);
-    const size_t smem = 2 * size_t(nz + 1) * sizeof(T);
+    const size_t smem = 2 * size_t(nz + 1) * sizeof(T) + (kADPark<T> ? size_t(CS2_AD_PARK_COUNT) * kColBlock * sizeof(T) : 0);
     const T tdt = static_cast<T>(dt);
     const NLK<T> kc = make_nlk<T>(p, dt, evap);
     const ExpK<T> xk = make_expk<T>();
     if (!fits_u32_offsets<T>(nz, ls)) return -2;
+    if (smem > size_t(160) * 1024) return -2;
+    int dev = 0;
+    if (smem > size_t(64) * 1024 && hipGetDevice(&dev) != hipSuccess) return -1;
     const bool reg = p.LREGCL != 0;
     const bool fix = p.AD_TRAJ_FIX != 0;
 #define CS2_AD_LAUNCH(R, F, E)                                                                                         \
-    hipLaunchKernelGGL((ad_kernel<T, R, F, E>), grid, block, smem, stream, e, kc, xk, nx, nz, ls, ci, ca, eta, co, coa, \
-                       tdt)
+    do {                                                                                                               \
+        auto kern = ad_kernel<T, R, F, E>;                                                                             \
+        if (smem > size_t(64) * 1024) { /* > 64 KB of dynamic LDS needs the opt-in: once per instantiation and device */ \
+            static size_t attr_set[64] = {};                                                                           \
+            if (attr_set[dev & 63] < smem) {                                                                           \
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                           \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, int(smem)) != hipSuccess)          \
+                    return -1;                                                                                         \
+                attr_set[dev & 63] = smem;                                                                             \
+            }                                                                                                          \
+        }                                                                                                              \
+        hipLaunchKernelGGL(kern, grid, block, smem, stream, e, kc, xk, nx, nz, ls, ci, ca, eta, co, coa, tdt);         \
+    } while (0)
 #define CS2_AD_LAUNCH_E(R, F) \
     do {                      \
         if (evap) CS2_AD_LAUNCH(R, F, true); else CS2_AD_LAUNCH(R, F, false); \

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 CSV output (gpurun_out/prof_*) into the small summaries kept under profiles/rNN/.
-  python profiles/summarize.py <tag> <round-dir>     e.g.  python profiles/summarize.py r01d profiles/r01"""
+  python profiles/summarize.py <tag> <round-dir>     e.g.  python profiles/summarize.py r02 profiles/r02"""
 import collections, csv, glob, json, os, sys
 
 tag, out = sys.argv[1], sys.argv[2]
@@ -28,28 +28,42 @@ def pmc(pattern, dest):
                 d[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, v in d.items():
             pm.setdefault(k, {}).update({c: {"mean_per_dispatch": sum(x) / len(x), "dispatches": len(x)} for c, x in v.items()})
-    json.dump(pm, open(dest, "w"), indent=1)
+    if pm:
+        json.dump(pm, open(dest, "w"), indent=1)
     return pm
 
 
-for r in stats(f"gpurun_out/prof_all_{tag}/trace/runc/*kernel_stats.csv", f"{out}/all_kernels_fp64_65536_kernel_stats.csv"):
-    print("bench_kernels.py:", r["Name"].split("(")[0][:48], r["Calls"], round(float(r["AverageNs"]) / 1e3, 1), "us")
-for r in stats(f"gpurun_out/prof_{tag}/trace/runc/*kernel_stats.csv", f"{out}/nl_fp64_65536_kernel_stats.csv"):
-    print("bench.py        :", r["Name"].split("(")[0][:48], r["Calls"], round(float(r["AverageNs"]) / 1e3, 1), "us")
-pmc(f"gpurun_out/prof_all_{tag}/pmc_*/runc/*counter_collection.csv", f"{out}/all_kernels_fp64_65536_pmc.json")
-pm = pmc(f"gpurun_out/prof_{tag}/pmc_*/runc/*counter_collection.csv", f"{out}/nl_fp64_65536_pmc.json")
-for k, v in pm.items():
-    fs = v.get("FETCH_SIZE", {}).get("mean_per_dispatch", 0) * 1024
-    ws = v.get("WRITE_SIZE", {}).get("mean_per_dispatch", 0) * 1024
-    line = f"{k[:48]}: FETCH_SIZE x2 = {2 * fs / 1e9:.3f} GB, WRITE_SIZE = {ws / 1e9:.3f} GB"
-    if "SQ_INSTS_VALU" in v:
-        wc, va, wa = (v[c]["mean_per_dispatch"] for c in ("SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY"))
-        line += f", VALU/wave {v['SQ_INSTS_VALU']['mean_per_dispatch'] / v['SQ_WAVES']['mean_per_dispatch']:.0f}, VALU-active {va / wc:.0%}, waiting {wa / wc:.0%}"
-    print(line)
+def show(pm):
+    for k, v in pm.items():
+        fs = v.get("FETCH_SIZE", {}).get("mean_per_dispatch", 0) * 1024
+        ws = v.get("WRITE_SIZE", {}).get("mean_per_dispatch", 0) * 1024
+        line = f"  {k[:56]}: FETCH_SIZE x2 = {2 * fs / 1e9:.3f} GB, WRITE_SIZE = {ws / 1e9:.3f} GB"
+        if "SQ_INSTS_VALU" in v and "SQ_WAVE_CYCLES" in v:
+            wc, va, wa = (v[c]["mean_per_dispatch"] for c in ("SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY"))
+            line += f", VALU/wave {v['SQ_INSTS_VALU']['mean_per_dispatch'] / v['SQ_WAVES']['mean_per_dispatch']:.0f}, VALU-active {va / wc:.0%}, waiting {wa / wc:.0%}"
+        print(line)
+
+
+for d in sorted(glob.glob(f"gpurun_out/prof_all_{tag}_*")):
+    sfx = d.split(f"prof_all_{tag}_")[1]                       # e.g. double_65536
+    prec, cols = sfx.split("_")
+    name = f"all_kernels_{'fp64' if prec == 'double' else 'fp32'}_{cols}"
+    for r in stats(f"{d}/trace/*/*kernel_stats.csv", f"{out}/{name}_kernel_stats.csv"):
+        print(f"bench_kernels.py {sfx}:", r["Name"].split("(")[0][:56], r["Calls"], round(float(r["AverageNs"]) / 1e3, 1), "us")
+    show(pmc(f"{d}/pmc_*/*/*counter_collection.csv", f"{out}/{name}_pmc.json"))
+for r in stats(f"gpurun_out/prof_{tag}/trace/*/*kernel_stats.csv", f"{out}/bench_fp64_65536_kernel_stats.csv"):
+    print("bench.py        :", r["Name"].split("(")[0][:56], r["Calls"], round(float(r["AverageNs"]) / 1e3, 1), "us")
+show(pmc(f"gpurun_out/prof_{tag}/pmc_*/*/*counter_collection.csv", f"{out}/nl_fp64_65536_pmc.json"))
 
 # the bench line printed by the profiled run itself (pass 1), for the stats-vs-events comparison
-for line in open(f"gpurun_out/prof_{tag}/trace.log", errors="replace"):
-    if line.startswith('{"metric"'):
-        d = json.loads(line)
-        json.dump(d, open(f"{out}/bench_under_rocprof.json", "w"))
-        print("profiled run's own events: avg_launch_ms", d["roofline"]["avg_launch_ms"], "ms_per_step", d["ms_per_step"])
+try:
+    for line in open(f"gpurun_out/prof_{tag}/trace.log", errors="replace"):
+        if line.startswith('{"metric"'):
+            d = json.loads(line)
+            json.dump(d, open(f"{out}/bench_under_rocprof.json", "w"))
+            for k in ("roofline", "roofline_tl", "roofline_ad", "roofline_nl_f32"):
+                if k in d:
+                    print(f"profiled run's own events: {k}: {d[k]['kernel']} avg_launch_ms {d[k]['avg_launch_ms']:.4f}")
+            print("ms_per_step", d["ms_per_step"])
+except OSError:
+    pass

@@ -1,0 +1,266 @@
+"""A dependency-free reader for the HDF5 files of the CLOUDSC2 data set (`data/input.h5`, `data/reference_*.h5`).
+
+The reference reads its inputs and golden outputs through `h5py` (/root/reference/src/cloudsc2_gt4py/iox.py:212-244 via
+`ifs_physics_common.iox.HDF5Operator`); `h5py` is not part of this image (nor of the GPU boxes), so the reader path of this
+build carries its own reader for exactly the subset of the HDF5 file format those files use - as written by the HDF5
+library with its default ("earliest") format settings:
+
+  * superblock version 0 / 1, 8-byte (or 4-byte) offsets and lengths;
+  * old-style groups: symbol-table message -> version-1 B-tree + local heap + symbol-table nodes (nested groups too);
+  * version-1 object headers with continuation blocks;
+  * dataspace versions 1 / 2 (simple, scalar), fixed-point and IEEE floating-point datatypes (little or big endian);
+  * data layout version 3 (and 1 / 2), classes COMPACT and CONTIGUOUS.
+
+Anything else (chunked or compressed datasets, new-style groups with link messages / fractal heaps, compound or
+variable-length types) raises `NotImplementedError` naming the feature - read such a file with h5py.  The interface is the
+part of h5py's the reader path uses: `File(path)` is a read-only mapping name -> NumPy array (`f["PT"]`, `f.keys()`,
+`name in f`), nested groups by "/"-separated names.  Format reference: "HDF5 File Format Specification Version 2.0".
+"""
+from __future__ import annotations
+
+import mmap
+import struct
+from collections.abc import Mapping
+from typing import Dict, Iterator, Tuple
+
+import numpy as np
+
+_SIGNATURE = b"\x89HDF\r\n\x1a\n"
+_UNDEF = {4: 0xFFFFFFFF, 8: 0xFFFFFFFFFFFFFFFF}
+
+
+class H5FormatError(ValueError):
+    pass
+
+
+class File(Mapping):
+    def __init__(self, filename: str, mode: str = "r") -> None:
+        if mode != "r":
+            raise ValueError("h5lite.File is read-only")
+        self.filename = filename
+        self._fh = open(filename, "rb")
+        self._buf = mmap.mmap(self._fh.fileno(), 0, access=mmap.ACCESS_READ)
+        self._datasets: Dict[str, Tuple[int, ...]] = {}
+        self._read_superblock()
+        self._walk_group(self._root_btree, self._root_heap, "")
+
+    # ------------------------------------------------------------------ mapping interface
+    def __getitem__(self, name: str) -> np.ndarray:
+        try:
+            addr = self._datasets[name.lstrip("/")]
+        except KeyError:
+            raise KeyError(f"{self.filename}: no dataset named {name!r}") from None
+        return self._read_dataset(addr, name)
+
+    def __iter__(self) -> Iterator[str]:
+        return iter(self._datasets)
+
+    def __len__(self) -> int:
+        return len(self._datasets)
+
+    def close(self) -> None:
+        self._buf.close()
+        self._fh.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ------------------------------------------------------------------ primitives
+    def _u(self, off: int, size: int) -> int:
+        return int.from_bytes(self._buf[off:off + size], "little")
+
+    def _offset(self, off: int) -> int:
+        return self._u(off, self._so)
+
+    def _length(self, off: int) -> int:
+        return self._u(off, self._sl)
+
+    def _read_superblock(self) -> None:
+        b = self._buf
+        base = 0
+        while b[base:base + 8] != _SIGNATURE:        # the superblock may sit at 0, 512, 1024, ... (user block)
+            base = 512 if base == 0 else base * 2
+            if base + 8 > len(b):
+                raise H5FormatError(f"{self.filename}: not an HDF5 file (signature not found)")
+        version = b[base + 8]
+        if version not in (0, 1):
+            raise NotImplementedError(f"{self.filename}: HDF5 superblock version {version} (written with libver='latest'?) "
+                                      "is outside the subset h5lite reads - use h5py")
+        self._so, self._sl = b[base + 13], b[base + 14]
+        if self._so not in (4, 8) or self._sl not in (4, 8):
+            raise H5FormatError(f"{self.filename}: offset / length sizes {self._so} / {self._sl}")
+        p = base + 24 + (4 if version == 1 else 0)   # v1 adds indexed-storage K + reserved
+        self._base = self._offset(p)
+        p += 4 * self._so                            # base, free-space, end-of-file, driver-info addresses
+        # root group symbol table entry: name offset, header address, cache type, reserved, scratch pad
+        header = self._offset(p + self._so)
+        cache_type = self._u(p + 2 * self._so, 4)
+        scratch = p + 2 * self._so + 8
+        if cache_type == 1:
+            self._root_btree, self._root_heap = self._offset(scratch), self._offset(scratch + self._so)
+        else:
+            self._root_btree, self._root_heap = self._group_addresses(header)
+
+    # ------------------------------------------------------------------ object headers
+    def _messages(self, addr: int):
+        """(type, offset, size) of every message of the version-1 object header at `addr` (continuations followed)."""
+        a = self._base + addr
+        if self._buf[a] != 1:
+            if self._buf[a:a + 4] == b"OHDR":
+                raise NotImplementedError(f"{self.filename}: version-2 object headers are outside the subset h5lite reads")
+            raise H5FormatError(f"{self.filename}: object header version {self._buf[a]} at {addr}")
+        nmsg = self._u(a + 2, 2)
+        size = self._u(a + 8, 4)
+        blocks = [(a + 16, size)]
+        out = []
+        while blocks and len(out) < nmsg:
+            p, remaining = blocks.pop(0)
+            end = p + remaining
+            while p + 8 <= end and len(out) < nmsg:
+                mtype, msize = self._u(p, 2), self._u(p + 2, 2)
+                body = p + 8
+                if mtype == 0x0010:                  # continuation: offset, length of another message block
+                    blocks.append((self._base + self._offset(body), self._length(body + self._so)))
+                out.append((mtype, body, msize))
+                p = body + msize
+        return out
+
+    def _group_addresses(self, header: int) -> Tuple[int, int]:
+        for mtype, body, _ in self._messages(header):
+            if mtype == 0x0011:                      # symbol table message: B-tree + local heap
+                return self._offset(body), self._offset(body + self._so)
+            if mtype in (0x0002, 0x0006):            # link info / link message: new-style group
+                raise NotImplementedError(f"{self.filename}: new-style groups (link messages) are outside the subset "
+                                          "h5lite reads - use h5py")
+        raise H5FormatError(f"{self.filename}: object at {header} is not a group")
+
+    # ------------------------------------------------------------------ groups
+    def _heap_string(self, heap: int, off: int) -> str:
+        h = self._base + heap
+        if self._buf[h:h + 4] != b"HEAP":
+            raise H5FormatError(f"{self.filename}: local heap signature missing at {heap}")
+        data = self._base + self._offset(h + 8 + 2 * self._sl)
+        end = self._buf.find(b"\0", data + off)
+        return self._buf[data + off:end].decode("utf-8")
+
+    def _walk_group(self, btree: int, heap: int, prefix: str) -> None:
+        n = self._base + btree
+        if self._buf[n:n + 4] != b"TREE":
+            raise H5FormatError(f"{self.filename}: B-tree signature missing at {btree}")
+        level, used = self._buf[n + 5], self._u(n + 6, 2)
+        p = n + 8 + 2 * self._so                     # keys / children: key0 child0 key1 ... keyN
+        for i in range(used):
+            child = self._offset(p + self._sl + i * (self._sl + self._so))
+            if level > 0:
+                self._walk_group(child, heap, prefix)
+            else:
+                self._walk_snod(child, heap, prefix)
+
+    def _walk_snod(self, addr: int, heap: int, prefix: str) -> None:
+        s = self._base + addr
+        if self._buf[s:s + 4] != b"SNOD":
+            raise H5FormatError(f"{self.filename}: symbol table node signature missing at {addr}")
+        count = self._u(s + 6, 2)
+        entry = 2 * self._so + 24
+        for i in range(count):
+            e = s + 8 + i * entry
+            name = self._heap_string(heap, self._offset(e))
+            header = self._offset(e + self._so)
+            cache_type = self._u(e + 2 * self._so, 4)
+            if cache_type == 1:                      # a group whose B-tree / heap are cached in the entry
+                sp = e + 2 * self._so + 8
+                self._walk_group(self._offset(sp), self._offset(sp + self._so), prefix + name + "/")
+                continue
+            types = {m[0] for m in self._messages(header)}
+            if 0x0011 in types:
+                bt, hp = self._group_addresses(header)
+                self._walk_group(bt, hp, prefix + name + "/")
+            elif 0x0008 in types:
+                self._datasets[prefix + name] = header
+
+    # ------------------------------------------------------------------ datasets
+    def _read_dataset(self, header: int, name: str) -> np.ndarray:
+        shape = dtype = None
+        layout = None
+        for mtype, body, msize in self._messages(header):
+            if mtype == 0x0001:
+                shape = self._dataspace(body)
+            elif mtype == 0x0003:
+                dtype = self._datatype(body, name)
+            elif mtype == 0x0008:
+                layout = (body, msize)
+            elif mtype == 0x000B:
+                raise NotImplementedError(f"{self.filename}:{name}: filtered (compressed) datasets are outside the subset "
+                                          "h5lite reads - use h5py")
+        if shape is None or dtype is None or layout is None:
+            raise H5FormatError(f"{self.filename}:{name}: dataspace / datatype / layout message missing")
+        count = int(np.prod(shape, dtype=np.int64)) if shape else 1
+        body = layout[0]
+        version = self._buf[body]
+        if version == 3:
+            cls = self._buf[body + 1]
+            if cls == 1:                             # contiguous: address, size
+                addr, size = self._offset(body + 2), self._length(body + 2 + self._so)
+                if addr == _UNDEF[self._so]:         # never written: fill value (0)
+                    return np.zeros(shape, dtype.newbyteorder("="))
+                start = self._base + addr
+            elif cls == 0:                           # compact: size (2 bytes), data
+                size, start = self._u(body + 2, 2), body + 4
+            else:
+                raise NotImplementedError(f"{self.filename}:{name}: chunked datasets are outside the subset h5lite reads "
+                                          "- use h5py")
+        elif version in (1, 2):
+            rank, cls = self._buf[body + 1], self._buf[body + 2]
+            if cls == 1:
+                start, size = self._base + self._offset(body + 8), count * dtype.itemsize
+            elif cls == 0:
+                p = body + 8 + 4 * rank
+                size, start = self._u(p, 4), p + 4
+            else:
+                raise NotImplementedError(f"{self.filename}:{name}: chunked datasets are outside the subset h5lite reads")
+        else:
+            raise NotImplementedError(f"{self.filename}:{name}: data layout message version {version}")
+        if size < count * dtype.itemsize:
+            raise H5FormatError(f"{self.filename}:{name}: {size} bytes stored, {count * dtype.itemsize} needed")
+        arr = np.frombuffer(self._buf, dtype=dtype, count=count, offset=start).reshape(shape)
+        return arr.astype(dtype.newbyteorder("="), copy=True)   # detached from the mapping, native byte order
+
+    def _dataspace(self, body: int) -> Tuple[int, ...]:
+        version, rank, flags = self._buf[body], self._buf[body + 1], self._buf[body + 2]
+        if version == 1:
+            p = body + 8
+        elif version == 2:
+            if self._buf[body + 3] == 2:
+                raise H5FormatError(f"{self.filename}: null dataspace")
+            p = body + 4
+        else:
+            raise NotImplementedError(f"{self.filename}: dataspace message version {version}")
+        del flags                                    # maximum dimensions, if present, follow the current ones: not needed
+        return tuple(self._length(p + i * self._sl) for i in range(rank))
+
+    def _datatype(self, body: int, name: str) -> np.dtype:
+        cls = self._buf[body] & 0x0F
+        bits0 = self._buf[body + 1]
+        size = self._u(body + 4, 4)
+        order = ">" if bits0 & 1 else "<"
+        if cls == 0:                                 # fixed point: bit 3 of the class bit field = signed
+            kind = "i" if bits0 & 0x08 else "u"
+        elif cls == 1:                               # floating point (IEEE layouts of 2 / 4 / 8 bytes are what NumPy has)
+            kind = "f"
+        else:
+            raise NotImplementedError(f"{self.filename}:{name}: datatype class {cls} is outside the subset h5lite reads "
+                                      "- use h5py")
+        if size not in (1, 2, 4, 8) or (kind == "f" and size == 1):
+            raise NotImplementedError(f"{self.filename}:{name}: {size}-byte {'float' if kind == 'f' else 'integer'}")
+        return np.dtype(f"{order}{kind}{size}")
+
+
+def is_hdf5(filename: str) -> bool:
+    try:
+        with open(filename, "rb") as fh:
+            return fh.read(8) == _SIGNATURE
+    except OSError:
+        return False

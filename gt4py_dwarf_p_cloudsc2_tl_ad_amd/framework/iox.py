@@ -2,10 +2,12 @@
 the call surface of /root/reference/src/cloudsc2_gt4py/iox.py:212-244 and setup.py:28-70.
 
 Data sources, in this order:
-  1. the HDF5 file itself when it exists AND `h5py` is importable (the real `data/input.h5` /
-     `reference_*.h5`);
-  2. for `reference_{double,single}.h5`: the .npz conversion committed under tests/golden/ (same
-     datasets), when h5py is missing;
+  1. the HDF5 file itself when it exists (the real `data/input.h5` / `reference_*.h5`): through `h5py` when it is
+     importable, otherwise through the build's own dependency-free reader `framework/h5lite.py` (contiguous,
+     uncompressed datasets in old-style groups - what the HDF5 library writes by default and what the reference's
+     golden files use);
+  2. for `reference_{double,single}.h5` when the file itself is absent (the GPU box): the .npz conversion committed
+     under tests/golden/ (same datasets);
   3. for the input file: the deterministic SYNTHETIC dataset (`synthetic.make_state`, provisional
      parameters) - `data/input.h5` is not shipped with the reference (.MISSING_LARGE_BLOBS:1).  A notice
      is printed once; every number produced from it is "synthetic-parameters".
@@ -84,7 +86,11 @@ def _open(filename: str) -> Mapping[str, Any]:
 
             return h5py.File(filename, "r")
         except ImportError:
-            pass
+            # no h5py in this image: the build's own reader for the subset of the format these files use
+            from . import h5lite
+
+            if h5lite.is_hdf5(filename):
+                return h5lite.File(filename)
     base = os.path.basename(filename)
     if base.startswith("reference_"):
         npz = os.path.join(_REPO, "tests", "golden", base.replace(".h5", ".npz"))

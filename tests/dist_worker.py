@@ -22,6 +22,26 @@ def main():
     from gt4py_dwarf_p_cloudsc2_tl_ad_amd.drivers import run_symmetry_test, run_taylor_test
 
     cols = sys.argv[1]
+    if len(sys.argv) > 2 and sys.argv[2] == "reader":
+        # reader path (`--input auto`): report this rank's first columns and eta, for the shard check of the test
+        import argparse
+
+        import numpy as np
+
+        from gt4py_dwarf_p_cloudsc2_tl_ad_amd import storage
+        from gt4py_dwarf_p_cloudsc2_tl_ad_amd.drivers._common import add_common_options, setup
+
+        ap = argparse.ArgumentParser()
+        add_common_options(ap)
+        ctx = setup(ap.parse_args(["--backend", "numpy", "--num-cols", cols, "--input", "auto"]))
+        st = ctx["state"]
+        t = storage.klayout(st["f_t"].data).numpy()
+        print("RESULT " + json.dumps({"rank": int(os.environ.get("RANK", "0")), "t_level50": t[50].tolist(),
+                                      "eta": np.asarray(st["f_eta"].data).tolist()}))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     t = run_taylor_test.main(["--backend", "numpy", "--num-cols", cols, "--input", "synthetic", "--disable-validation"])
     s = run_symmetry_test.main(["--backend", "numpy", "--num-cols", cols, "--input", "synthetic", "--ad-traj-fix"])
     if int(os.environ.get("RANK", "0")) == 0:

@@ -85,3 +85,29 @@ def test_reader_path_shards_are_slices_of_the_tiled_global_problem():
             .get_field((I, J, K), "float", "", "PT", (K, IJ), (IJ, ExpandedDim, K))
         assert np.array_equal(part.data[:, 0, :].numpy(), w[rank * nx:(rank + 1) * nx]), rank
     assert not np.array_equal(w[:nx], w[nx:2 * nx])                               # the two shards differ
+
+
+def test_reader_path_under_two_gloo_ranks():
+    """The drivers' own set-up (`drivers/_common.setup`, `--input auto`) under torch.distributed with two ranks: rank r holds
+    the global columns [r nx, (r+1) nx) of the tiled 100-column dataset, and both ranks hold the SAME eta (global column 0)."""
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    port = str(_free_port())
+    nx = 130
+    procs = []
+    for rank in range(2):
+        e = {**env, "WORLD_SIZE": "2", "RANK": str(rank), "LOCAL_RANK": str(rank), "MASTER_ADDR": "127.0.0.1",
+             "MASTER_PORT": port}
+        procs.append(subprocess.Popen([sys.executable, WORKER, str(nx), "reader"], stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True, env=e))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (o, err) in zip(procs, outs):
+        assert p.returncode == 0, err[-3000:]
+    res = sorted((_result(o) for o, _ in outs), key=lambda r: r["rank"])
+    single = subprocess.run([sys.executable, WORKER, str(2 * nx), "reader"], capture_output=True, text=True, timeout=600,
+                            env={**env, "WORLD_SIZE": "1", "RANK": "0"})
+    assert single.returncode == 0, single.stderr[-3000:]
+    whole = _result(single.stdout)
+    t = np.array(whole["t_level50"])
+    assert np.array_equal(np.array(res[0]["t_level50"]), t[:nx]) and np.array_equal(np.array(res[1]["t_level50"]), t[nx:])
+    assert np.array_equal(t[100:200], t[0:100]) and not np.array_equal(t[:nx], t[nx:])
+    assert res[0]["eta"] == res[1]["eta"] == whole["eta"]

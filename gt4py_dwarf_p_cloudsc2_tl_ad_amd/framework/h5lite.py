@@ -8,7 +8,8 @@ library with its default ("earliest") format settings:
   * superblock version 0 / 1, 8-byte (or 4-byte) offsets and lengths;
   * old-style groups: symbol-table message -> version-1 B-tree + local heap + symbol-table nodes (nested groups too);
   * version-1 object headers with continuation blocks;
-  * dataspace versions 1 / 2 (simple, scalar), fixed-point and IEEE floating-point datatypes (little or big endian);
+  * dataspace versions 1 / 2 (simple, scalar); fixed-point and IEEE floating-point datatypes (little or big endian),
+    enumerations (returned in their base integer type - h5py writes booleans so) and fixed-length strings (raw bytes);
   * data layout version 3 (and 1 / 2), classes COMPACT and CONTIGUOUS.
 
 Anything else (chunked or compressed datasets, new-style groups with link messages / fractal heaps, compound or
@@ -205,7 +206,7 @@ class File(Mapping):
             if cls == 1:                             # contiguous: address, size
                 addr, size = self._offset(body + 2), self._length(body + 2 + self._so)
                 if addr == _UNDEF[self._so]:         # never written: fill value (0)
-                    return np.zeros(shape, dtype.newbyteorder("="))
+                    return np.zeros(shape, dtype if dtype.kind == "S" else dtype.newbyteorder("="))
                 start = self._base + addr
             elif cls == 0:                           # compact: size (2 bytes), data
                 size, start = self._u(body + 2, 2), body + 4
@@ -226,7 +227,8 @@ class File(Mapping):
         if size < count * dtype.itemsize:
             raise H5FormatError(f"{self.filename}:{name}: {size} bytes stored, {count * dtype.itemsize} needed")
         arr = np.frombuffer(self._buf, dtype=dtype, count=count, offset=start).reshape(shape)
-        return arr.astype(dtype.newbyteorder("="), copy=True)   # detached from the mapping, native byte order
+        native = dtype if dtype.kind == "S" else dtype.newbyteorder("=")
+        return arr.astype(native, copy=True)         # detached from the mapping, native byte order
 
     def _dataspace(self, body: int) -> Tuple[int, ...]:
         version, rank, flags = self._buf[body], self._buf[body + 1], self._buf[body + 2]
@@ -250,6 +252,10 @@ class File(Mapping):
             kind = "i" if bits0 & 0x08 else "u"
         elif cls == 1:                               # floating point (IEEE layouts of 2 / 4 / 8 bytes are what NumPy has)
             kind = "f"
+        elif cls == 3:                               # fixed-length string: raw bytes, `size` per element
+            return np.dtype(f"S{size}")
+        elif cls == 8:                               # enumeration (h5py stores booleans so): values in the base integer type,
+            return self._datatype(body + 8, name)    # whose own datatype message opens the properties
         else:
             raise NotImplementedError(f"{self.filename}:{name}: datatype class {cls} is outside the subset h5lite reads "
                                       "- use h5py")

@@ -1,6 +1,6 @@
 """Writes tests/golden/h5lite_fixture.h5 (+ .npz with the same arrays): a small HDF5 file of the build's OWN data that
 exercises what framework/h5lite.py reads - many root datasets (several symbol-table nodes / B-tree entries), nested groups,
-1-3-D float64 / float32 / int64 / int32 / uint8, big-endian data, a scalar and a compact dataset, a never-written dataset -
+1-3-D float64 / float32 / int64 / int32 / uint8, big-endian data, an enumeration (booleans), fixed-length strings, a scalar and a compact dataset, a never-written dataset -
 plus one chunked+gzip dataset that h5lite must refuse.  Run with an interpreter that has h5py
 (`/opt/conda/bin/python3.9 tests/golden/make_h5lite_fixture.py`); the tests read the committed files."""
 import os
@@ -17,6 +17,8 @@ data["KLEV"] = np.array([137], dtype=np.int64)
 data["KLON"] = np.array([100], dtype=np.int32)
 data["CUBE"] = rng.integers(0, 255, size=(3, 4, 5)).astype(np.uint8)
 data["BIG_ENDIAN"] = np.arange(12, dtype=">f8").reshape(3, 4)
+data["LOGICAL"] = np.array([True, False, True])          # h5py: enumeration over int8
+data["NAME"] = np.array([b"cloudsc2", b"hip"], dtype="S8")  # fixed-length strings
 data["grp/inner/T"] = rng.normal(size=(6,))
 data["grp/Q"] = rng.normal(size=(2, 3)).astype(np.float32)
 path = os.path.join(HERE, "h5lite_fixture.h5")

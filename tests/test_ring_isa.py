@@ -1,7 +1,9 @@
 """The hand-counted `s_waitcnt vmcnt(N)` of the cloudsc2_tl LDS-ring kernel is only right if the compiled level loop
 issues exactly the operations the count assumes: NI LDS-DMAs and 20 stores per level, and no wait hipcc added on its own.
 This test compiles csrc/cloudsc2_tl.hip to gfx950 assembly (no GPU needed) and checks exactly that, so a compiler or source
-change that breaks the count fails here and not as silent data corruption on the GPU."""
+change that breaks the count fails here and not as silent data corruption on the GPU.  (nl_ring_kernel's wait is one level of
+stores short of exact by design and hipcc multiplies its loop body per load-policy path, so a static count says nothing
+there; its guard is the determinism soak and the ring-vs-register tests on the GPU.)"""
 import os
 import re
 import subprocess
@@ -13,14 +15,18 @@ CSRC = os.path.join(ROOT, "gt4py_dwarf_p_cloudsc2_tl_ad_amd", "csrc")
 HIPCC = "/opt/rocm/bin/hipcc"
 
 
-@pytest.fixture(scope="module")
-def tl_asm(tmp_path_factory):
+def _compile(tmp_path_factory, src):
     if not os.path.exists(HIPCC):
         pytest.skip("hipcc not available on this machine (the prebuilt library travelled with the snapshot)")
-    out = tmp_path_factory.mktemp("isa") / "tl.s"
-    subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S", "cloudsc2_tl.hip",
+    out = tmp_path_factory.mktemp("isa") / (src + ".s")
+    subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S", src,
                     "-o", str(out)], cwd=CSRC, check=True, capture_output=True)
     return out.read_text()
+
+
+@pytest.fixture(scope="module")
+def tl_asm(tmp_path_factory):
+    return _compile(tmp_path_factory, "cloudsc2_tl.hip")
 
 
 def _kernels(asm, prefix):
@@ -31,13 +37,14 @@ def _kernels(asm, prefix):
             yield name, asm[m.end():end].split("\n")
 
 
-def _innermost_loop_around(lines, idx):
+def _innermost_loop_around(lines, idx, outermost=False):
     labels = {m.group(1): i for i, l in enumerate(lines) if (m := re.match(r"(\.LBB\d+_\d+):", l.strip()))}
     best = None
     for i, l in enumerate(lines):
         m = re.match(r"\s*s_c?branch\w* (\.LBB\d+_\d+)", l)
         if m and m.group(1) in labels and labels[m.group(1)] <= idx <= i:
-            if best is None or (i - labels[m.group(1)]) < (best[1] - best[0]):
+            smaller = best is None or (i - labels[m.group(1)]) < (best[1] - best[0])
+            if best is None or smaller != outermost:
                 best = (labels[m.group(1)], i)
     return best
 
@@ -61,3 +68,4 @@ def test_tl_ring_loop_matches_the_hand_counted_wait(tl_asm, tname, ni):
         assert set(vm_waits) - {str(ni)} == {"0", "63", str(expected)} and vm_waits.count("0") == 1, (name, vm_waits)
         seen += 1
     assert seen == 4              # REG x EVAP instantiations
+

@@ -895,7 +895,7 @@ ad_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
         pin_vgpr(xk.c5); pin_vgpr(xk.c4); pin_vgpr(xk.c3);
     }
 
-    const int gcol = blockIdx.x * kColBlock + threadIdx.x;
+    const int gcol = xcd_block() * kColBlock + threadIdx.x;
     // CS2_AD_PARK: this lane's parking slots follow the level table (8-byte aligned)
     T* const park_lds = s_scalm + (nz + 1) + threadIdx.x;
     (void)park_lds;

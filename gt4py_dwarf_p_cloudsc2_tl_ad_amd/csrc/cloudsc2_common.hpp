@@ -27,6 +27,21 @@ constexpr int kWave = 64;  // CDNA wavefront
 #endif
 constexpr int kColBlock = CS2_COL_BLOCK;
 
+// XCD-aware workgroup -> column-block mapping.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8
+// share one, MI355X_MICROARCH.md "Workgroup dispatch"); with the identity mapping every XCD's L2 and fabric port sees
+// every eighth 2-KB piece of each field row.  Remapped, the workgroups of one XCD own one contiguous eighth of the
+// columns.  Measured on cloudsc2_nl (profiles/r02/ab_xcd_remap.txt, one process): neutral at 65 536 fp64 columns (one
+// workgroup per CU, everything in lockstep), -1.4 .. -2.2 % at 262 144 fp64 / 524 288 fp32 columns.  Grids that are not
+// a multiple of 8 keep the identity mapping (every block index must stay below gridDim.x).
+#ifndef CS2_XCD_REMAP
+#define CS2_XCD_REMAP 1
+#endif
+__device__ __forceinline__ int xcd_block() {
+    const int b = blockIdx.x, n = gridDim.x;
+    if (CS2_XCD_REMAP && (n & 7) == 0) return (b & 7) * (n >> 3) + (b >> 3);
+    return b;
+}
+
 // ---- math in the working precision --------------------------------------------------------
 template <typename T> __device__ __forceinline__ T rexp(T x);
 template <> __device__ __forceinline__ double rexp<double>(double x) { return exp(x); }

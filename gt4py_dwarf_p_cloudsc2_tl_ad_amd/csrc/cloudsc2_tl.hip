@@ -564,7 +564,7 @@ tl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
         pin_vgpr(xk.c5); pin_vgpr(xk.c4); pin_vgpr(xk.c3);
     }
 
-    const int gcol = blockIdx.x * kColBlock + threadIdx.x;
+    const int gcol = xcd_block() * kColBlock + threadIdx.x;
     const bool live = gcol < nx;
     const int col = live ? gcol : nx - 1;
     const uint32_t lsb = uint32_t(ls) * uint32_t(sizeof(T));
@@ -738,7 +738,7 @@ tl_ring_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtr
         pin_vgpr(xk.c5); pin_vgpr(xk.c4); pin_vgpr(xk.c3);
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int wcol0 = blockIdx.x * kColBlock + wave * 64;   // first column of this wave
+    const int wcol0 = xcd_block() * kColBlock + wave * 64;   // first column of this wave
     if (wcol0 >= nx) return;                                // nx % 64 == 0 (launcher): whole waves retire; the only
                                                             // workgroup barrier is inside build_level_table
     const uint32_t lsb = uint32_t(ls) * uint32_t(sizeof(T));

@@ -421,8 +421,8 @@ def main(argv=None):
     nl_kernel_name = None
     extra = {}
     if not args.no_roofline_events:
-        for _ in range(20):          # untimed: bring the GPU out of its idle power state first
-            step()
+        for _ in range(70):          # untimed, >= 25 ms of the same work: the GPU needs 10-15 ms after an idle period to
+            step()                   # reach its steady clocks (profiles/r02/window_probe.txt); 20 steps were not enough
         nl_kernel_name = last_kernel()
         reps = max(10, min(args.steps, 50))
         nl_ms = event_times(nl_only, reps, before=sat_only)

@@ -1,4 +1,4 @@
-"""The plain-C + OpenMP restatement (oracle/cloudsc2_nl_omp.c, the strong CPU baseline of bench.py) against the
+"""The plain-C + OpenMP restatement (oracle/cloudsc2_nl_omp.c, the multi-threaded CPU baseline of bench.py - a plain port, not a tuned CPU code) against the
 NumPy oracle, which is itself bit-identical to the executed reference source (tests/test_reference_exec.py).
 Both evaluate the same IEEE-double statements (the C build uses -ffp-contract=off); what is left are libm-vs-NumPy
 exp/tanh/pow differences (<= 1 ulp each) amplified through cancellations - hence 1e-12 of each field's scale."""

@@ -47,6 +47,17 @@ def test_config5_is_the_fixed_fp32_problem_split_over_the_gpus():
     assert d1["config"]["columns_per_gpu"] == 4194304 and d1["n_gpus"] == 1 and d1["rccl_ranks"] is None
 
 
+def test_eight_ranks_config5_rehearsal():
+    """The shape of the driver's 8-GPU scaling run of BASELINE configs[4], rehearsed on gloo: 8 ranks x 524 288 columns."""
+    p = _run("--gpus", "8", "--config", "5", "--dry-run")
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["rccl_ranks"] == 8 and d["config"]["columns_per_gpu"] == 524288
+    assert d["shard_check"]["col0_sum"] == 524288.0 * sum(range(8))          # ranks own columns [r * 524288, (r+1) * 524288)
+
+
 def test_world_size_mismatch_and_bad_splits_are_refused():
     p = _run("--gpus", "2", "--dry-run", env={"WORLD_SIZE": "3", "RANK": "0"})
     assert p.returncode != 0 and "WORLD_SIZE=3" in (p.stderr + p.stdout)

@@ -74,3 +74,27 @@ def test_launcher_parent_never_imports_torch():
     assert "import torch" not in head
     main_src = src[src.index("def main("):]
     assert main_src.index("launch_ranks(args, argv)") < main_src.index("import torch")
+
+
+@pytest.mark.gpu
+def test_bench_line_carries_the_contract_on_the_gpu(gpu):
+    """`python bench.py` (small sizes for speed) as a child process on the GPU: ONE JSON line with the driver's contract
+    keys, the `roofline` / `roofline_tl` / `roofline_ad` / `roofline_nl_f32` objects and a `cpu_baseline`."""
+    p = _run("--steps", "3", "--warmup", "1", "--cpu-cols", "256")
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert d["unit"] == "columns/s" and d["value"] > 1e7 and d["outputs_finite"] is True
+    assert "workload" in d["config"] and "model" not in d["config"]
+    for k in ("roofline", "roofline_tl", "roofline_ad", "roofline_nl_f32"):
+        r = d[k]
+        assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and 0.2 < r["frac"] < 1.0, (k, r)
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["kernel"].startswith("cs2::")
+    assert d["roofline"]["kernel"] == "cs2::nl_ring_kernel" and d["roofline_tl"]["kernel"] == "cs2::tl_kernel"
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
+    assert d["fused_step"]["results_equal_unfused"] is True

@@ -861,7 +861,10 @@ int launch_tl(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
         ring = ring && rsmem <= size_t(160) * 1024;   // LDS of a CU; very tall columns take the register path
         int dev = 0;
         if (ring && hipGetDevice(&dev) != hipSuccess) return -1;
-        if (ring && sizeof(T) == 8) {
+#ifndef CS2_TL_RING_ALWAYS
+#define CS2_TL_RING_ALWAYS 0   // A/B switch: 1 = take the ring whenever it is legal, whatever the occupancy
+#endif
+        if (ring && sizeof(T) == 8 && !CS2_TL_RING_ALWAYS) {
             // fp64 (two slots per wave = the register path's one level ahead): the ring wins wherever part of the chip is
             // latency-bound - 8 192 .. 49 152 columns -3.5 .. -6 %, 98 304 (1.5 workgroups per CU) -3.7 % - and loses
             // 1.5-2 % when every CU holds the same number of workgroups for the whole launch and HBM is saturated

@@ -65,6 +65,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-roofline-events", action="store_true")
     ap.add_argument("--no-extra-rooflines", action="store_true",
                     help="skip the TL / AD / fp32-NL kernel legs (N = 1 only)")
+    ap.add_argument("--placement", choices=["tuned", "arena", "separate"], default="tuned",
+                    help="where the step's 26 fields sit in HBM: 'tuned' (default) = storage.tune_placement calibrates the "
+                         "spacing between field starts for this process with the step itself as the objective, before the "
+                         "timed region; 'arena' = the default FieldArena layout; 'separate' = one torch allocation per field")
     ap.add_argument("--dry-run", action="store_true",
                     help="plumbing rehearsal without a GPU: gloo instead of RCCL, shard bookkeeping and the "
                          "reductions only, NO kernels (value is null) - used by the CPU tests of the launcher")
@@ -370,16 +374,35 @@ def main(argv=None):
     # resident state: this rank's slice [rank*nx, (rank+1)*nx) of the global problem
     s = make_resident_state(total, nz, rank * nx, nx, np_dtype, device)
     eta = torch.as_tensor(eta_levels(nz, dtype=np_dtype), device=device)  # from GLOBAL column 0
-    f = {k: storage.logical_view(v) for k, v in s.items()}
-    qsat = storage.zeros(nx, nz, np_dtype, device)
-    ins = {"in_" + k[2:]: v for k, v in f.items()}
-    ins["in_qsat"] = qsat
-    outs = {"out_" + n: storage.zeros(nx, nz, np_dtype, device) for n in NL_OUT}
     sat = compile_stencil("saturation", ext)
     nl = compile_stencil("cloudsc2_nl", ext)
 
+    def step_on(F):
+        sat(in_ap=F["in_ap"], in_t=F["in_t"], out_qsat=F["in_qsat"], domain=(nx, 1, nz), **com)
+        nl(**F, in_eta=eta, dt=dt, domain=(nx, 1, nz + 1), **com)
+
+    # Placement of the step's 26 fields in HBM (gt4py_dwarf_p_cloudsc2_tl_ad_amd/storage.py: FieldArena, tune_placement).
+    # The kernels, their arguments and their results are the same for every placement; what changes is how the 26
+    # concurrent streams fall onto HBM channels and banks.
+    order = ["in_" + n for n in NL_IN] + ["out_" + n for n in NL_OUT]
+    sources = {"in_" + k[2:]: v for k, v in s.items()}
+    placement = {"mode": args.placement}
+    if args.placement == "tuned":
+        F, rep = storage.tune_placement(nx, nz, np_dtype, device, order, sources, step_on)
+        placement.update(rep)
+    else:
+        old_cap = storage.set_arena_capacity(32 if args.placement == "arena" else 0)
+        F = {k: storage.from_klayout(v, np_dtype, device) for k, v in sources.items()}
+        F["in_qsat"] = storage.zeros(nx, nz, np_dtype, device)
+        F.update({"out_" + n: storage.zeros(nx, nz, np_dtype, device) for n in NL_OUT})
+        storage.set_arena_capacity(old_cap)
+    del s, sources
+    ins = {k: v for k, v in F.items() if k.startswith("in_")}
+    outs = {k: v for k, v in F.items() if k.startswith("out_")}
+    qsat = F["in_qsat"]
+
     def sat_only():
-        sat(in_ap=f["f_ap"], in_t=f["f_t"], out_qsat=qsat, domain=(nx, 1, nz), **com)
+        sat(in_ap=F["in_ap"], in_t=F["in_t"], out_qsat=qsat, domain=(nx, 1, nz), **com)
 
     def nl_only():
         nl(**ins, **outs, in_eta=eta, dt=dt, domain=(nx, 1, nz + 1), **com)
@@ -452,49 +475,78 @@ def main(argv=None):
             out = {}
             Z = lambda: storage.zeros(nx, nz, np_dtype, device)  # noqa: E731
             extn = dict(ext, NLEV=nz)
+            KL = storage.klayout
+            tuned = args.placement == "tuned"
+
+            def placed(order, sources, launch):
+                """fields of a leg: tuned placement (objective = the leg's own launch) or the default arenas"""
+                if tuned:
+                    return storage.tune_placement(nx, nz, np_dtype, device, order, sources, launch)
+                Fd = {k: (storage.from_klayout(sources[k], np_dtype, device) if sources.get(k) is not None else Z())
+                      for k in order}
+                return Fd, {"mode": args.placement}
+
             inc_out = {"out_" + n + "_i": Z() for n in INC}
             compile_stencil("state_increment", {"IGNORE_SUPSAT": True})(
                 **{"in_" + n: ins["in_" + n] for n in INC}, **inc_out, f=0.01, domain=(nx, 1, nz + 1), **com)
-            fi = {"in_" + n + "_i": inc_out["out_" + n + "_i"] for n in NL_IN}
-            tl_out = {"out_" + n: Z() for n in NL_OUT}
-            tl_out.update({"out_" + n + "_i": Z() for n in NL_OUT})
             tl = compile_stencil("cloudsc2_tl", extn)
-            tl_call = lambda: tl(**ins, **fi, **tl_out, in_eta=eta, dt=dt, domain=(nx, 1, nz + 1), **com)  # noqa: E731
+            tl_order = (["in_" + n for n in NL_IN] + ["in_" + n + "_i" for n in NL_IN] + ["out_" + n for n in NL_OUT]
+                        + ["out_" + n + "_i" for n in NL_OUT])
+            tl_src = {"in_" + n: KL(ins["in_" + n]) for n in NL_IN}
+            tl_src.update({"in_" + n + "_i": KL(inc_out["out_" + n + "_i"]) for n in NL_IN})
+            tl_launch = lambda Ft: tl(**Ft, in_eta=eta, dt=dt, domain=(nx, 1, nz + 1), **com)  # noqa: E731
+            Ft, tl_rep = placed(tl_order, tl_src, tl_launch)
+            del inc_out, tl_src
+            tl_call = lambda: tl_launch(Ft)  # noqa: E731
             for _ in range(3):
                 tl_call()
             tl_name = last_kernel()
             tl_ms = event_times(tl_call, 20)
-            out["roofline_tl"] = roofline_entry(tl_name, TLAD_WORDS_PER_COL, wsize, nx, args.precision, tl_ms)
-            ad_in = {"in_" + n + "_i": tl_out["out_" + n + "_i"] for n in NL_OUT}
-            ad_out = {"out_" + n: tl_out["out_" + n] for n in NL_OUT}
-            ad_out.update({"out_" + n + "_i": Z() for n in NL_IN})
+            out["roofline_tl"] = roofline_entry(tl_name, TLAD_WORDS_PER_COL, wsize, nx, args.precision, tl_ms, placement=tl_rep)
             ad = compile_stencil("cloudsc2_ad", extn)
-            ad_call = lambda: ad(**ins, **ad_in, **ad_out, in_eta=eta, dt=dt, domain=(nx, 1, nz + 1), **com)  # noqa: E731
+            ad_order = (["in_" + n for n in NL_IN] + ["in_" + n + "_i" for n in NL_OUT] + ["out_" + n for n in NL_OUT]
+                        + ["out_" + n + "_i" for n in NL_IN])
+            ad_src = {"in_" + n: KL(ins["in_" + n]) for n in NL_IN}
+            ad_src.update({"in_" + n + "_i": KL(Ft["out_" + n + "_i"]) for n in NL_OUT})      # forced with the TL perturbations
+            ad_launch = lambda Fa: ad(**Fa, in_eta=eta, dt=dt, domain=(nx, 1, nz + 1), **com)  # noqa: E731
+            Fa, ad_rep = placed(ad_order, ad_src, ad_launch)
+            del Ft, ad_src
+            ad_call = lambda: ad_launch(Fa)  # noqa: E731
             for _ in range(3):
                 ad_call()
             ad_name = last_kernel()
             ad_ms = event_times(ad_call, 20)
-            out["roofline_ad"] = roofline_entry(ad_name, TLAD_WORDS_PER_COL, wsize, nx, args.precision, ad_ms)
-            del inc_out, fi, tl_out, ad_in, ad_out
+            out["roofline_ad"] = roofline_entry(ad_name, TLAD_WORDS_PER_COL, wsize, nx, args.precision, ad_ms, placement=ad_rep)
+            del Fa
             # cloudsc2_nl fp32 at the per-GPU shard of BASELINE configs[4] on 8 GPUs (524 288 columns)
             n32 = CONFIG5_COLUMNS // 8
             s32 = make_resident_state(n32, nz, 0, n32, np.float32, device)
             eta32 = torch.as_tensor(eta_levels(nz, dtype=np.float32), device=device)
-            in32 = {"in_" + k[2:]: storage.logical_view(v) for k, v in s32.items()}
-            in32["in_qsat"] = storage.zeros(n32, nz, np.float32, device)
-            out32 = {"out_" + n: storage.zeros(n32, nz, np.float32, device) for n in NL_OUT}
-            sat32 = lambda: sat(in_ap=in32["in_ap"], in_t=in32["in_t"], out_qsat=in32["in_qsat"],  # noqa: E731
+
+            def step32(F32):
+                sat(in_ap=F32["in_ap"], in_t=F32["in_t"], out_qsat=F32["in_qsat"], domain=(n32, 1, nz), **com)
+                nl(**F32, in_eta=eta32, dt=dt, domain=(n32, 1, nz + 1), **com)
+
+            src32 = {"in_" + k[2:]: v for k, v in s32.items()}
+            if tuned:
+                F32, rep32 = storage.tune_placement(n32, nz, np.float32, device, order, src32, step32)
+            else:
+                F32 = {k: storage.from_klayout(v, np.float32, device) for k, v in src32.items()}
+                F32["in_qsat"] = storage.zeros(n32, nz, np.float32, device)
+                F32.update({"out_" + n: storage.zeros(n32, nz, np.float32, device) for n in NL_OUT})
+                rep32 = {"mode": args.placement}
+            del s32, src32
+            sat32 = lambda: sat(in_ap=F32["in_ap"], in_t=F32["in_t"], out_qsat=F32["in_qsat"],  # noqa: E731
                                 domain=(n32, 1, nz), **com)
-            nl32 = lambda: nl(**in32, **out32, in_eta=eta32, dt=dt, domain=(n32, 1, nz + 1), **com)  # noqa: E731
+            nl32 = lambda: nl(**F32, in_eta=eta32, dt=dt, domain=(n32, 1, nz + 1), **com)  # noqa: E731
             for _ in range(3):
-                sat32()
-                nl32()
+                step32(F32)
             name32 = last_kernel()
             ms32 = event_times(nl32, 10, before=sat32)
-            out["roofline_nl_f32"] = roofline_entry(name32, NL_WORDS_PER_COL, 4, n32, "single", ms32,
+            out["roofline_nl_f32"] = roofline_entry(name32, NL_WORDS_PER_COL, 4, n32, "single", ms32, placement=rep32,
                                                       what="per-GPU shard of BASELINE configs[4] on 8 GPUs, timed "
                                                            "inside the (saturation, cloudsc2_nl) pattern")
-            del s32, in32, out32
+            del F32
             torch.cuda.empty_cache()
             return out
 
@@ -573,6 +625,7 @@ def main(argv=None):
                           ranks=dist.get_world_size() if dist is not None else None,
                           backend="nccl (RCCL)" if dist is not None else "none (single process)")
         res["prewarm_steps"] = prewarm
+        res["placement"] = placement
         res["outputs_finite"] = finite
         res["validation_norm"] = dict(zip(NL_OUT, norm))
         if nl_ms is not None:

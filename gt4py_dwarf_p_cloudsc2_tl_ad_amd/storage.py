@@ -9,10 +9,22 @@ request) exposed as the permuted view ``(nx, 1, nz+1)`` - the same indexing work
 All 3-D storages have nz+1 levels, as in the reference (every kernel runs on
 ``domain=(nx, 1, nz+1)``, nonlinear/microphysics.py:168-169); K-vectors (`f_eta`, `klevel`) have nz+1
 entries too.
+
+Placement in HBM (`FieldArena`, `tune_placement`).  A stencil call streams 26 (NL) to 72 (AD) fields
+concurrently, every wave touching the same (level, column) offset of each of them at about the same time, so how the
+fields' starting addresses relate decides how those requests fall onto HBM channels, banks and rows.  Measured with the
+kernels unchanged (profiles/r02/placement_*.txt, layout_scan*.txt): the same fields run cloudsc2_nl anywhere between 295
+and 350 us depending on placement alone; separate `torch` allocations (the default: `zeros` / `from_klayout`) land anywhere
+in that range from process to process; slabs of ONE allocation behave the same in every process, and a per-field stagger
+of 2 304 B is worth 3 % over none, but which spacing between the slabs is fastest depends on where the driver put the
+arena - so `tune_placement` measures it, with the caller's own kernel sequence as the objective (bench.py does, before its
+timed region).  `CLOUDSC2_FIELD_ARENA=<n>` makes `zeros` / `from_klayout` draw GPU fields from automatic arenas of n slabs
+(off by default: the default arena layout is reproducible, not faster on average than separate allocations).
 """
 from __future__ import annotations
 
-from typing import Any, Tuple
+import os
+from typing import Any, Dict, Optional, Tuple
 
 import numpy as np
 import torch
@@ -45,9 +57,187 @@ def klayout(field: torch.Tensor) -> torch.Tensor:
     return field.permute(2, 1, 0).squeeze(1)
 
 
+class FieldArena:
+    """`capacity` field slabs of shape (nz+1, nx) in ONE allocation: slab i starts at a 2 MB boundary of the address space
+    + (i * stagger) mod 64 KB.  `zeros()` hands out the next slab as a zero-initialised logical (nx, 1, nz+1) field."""
+
+    SLAB_ALIGN = 2 << 20
+    STAGGER = 2304            # bytes; 9 x 256: coprime with the 256 channel slots of a 64 KB window
+    STAGGER_WRAP = 65536
+
+    def __init__(self, nx: int, nz: int, dtype: Any, device: Any, capacity: int, stagger: Optional[int] = None,
+                 extra_spacing: int = 0) -> None:
+        self.nx, self.nz, self.capacity = int(nx), int(nz), int(capacity)
+        self.dtype = torch_dtype(dtype)
+        self.device = torch.device(device)
+        self.stagger = self.STAGGER if stagger is None else int(stagger)
+        item = torch.empty((), dtype=self.dtype).element_size()
+        if self.stagger % 16 or self.capacity < 1:
+            raise ValueError("stagger must be a multiple of 16 bytes (the kernels' 16-byte load paths), capacity >= 1")
+        fbytes = (self.nz + 1) * self.nx * item
+        self.slab = -(-(fbytes + self.STAGGER_WRAP) // self.SLAB_ALIGN) * self.SLAB_ALIGN + int(extra_spacing)
+        self._item = item
+        self._buf = torch.zeros((self.capacity * self.slab + self.SLAB_ALIGN) // item, dtype=self.dtype, device=self.device)
+        self._base = (-self._buf.data_ptr()) % self.SLAB_ALIGN
+        self._next = 0
+
+    @property
+    def free_slots(self) -> int:
+        return self.capacity - self._next
+
+    def offset_of(self, slot: int) -> int:
+        """byte offset of slab `slot` from the arena's first 2 MB boundary"""
+        return slot * self.slab + (slot * self.stagger) % self.STAGGER_WRAP
+
+    def zeros(self) -> torch.Tensor:
+        if self._next >= self.capacity:
+            raise RuntimeError(f"FieldArena is full ({self.capacity} fields)")
+        o = (self._base + self.offset_of(self._next)) // self._item
+        self._next += 1
+        n = (self.nz + 1) * self.nx
+        return logical_view(self._buf[o:o + n].view(self.nz + 1, self.nx))
+
+
+def tune_placement(nx: int, nz: int, dtype: Any, device: Any, order, sources, launch, *, spacings=tuple(range(0, 64)),
+                   staggers=(FieldArena.STAGGER, 8448), launches: int = 5, rounds: int = 3, budget_s: float = 2.5):
+    """Calibrate WHERE the fields of a stencil call sit in HBM, for this process.
+
+    The rate at which a call streams its 26-72 fields depends on how their starting addresses relate (channel, bank and
+    row bits of 26+ concurrent streams) - by ~10 % between good and bad relations - and the best spacing between field
+    starts differs from process to process, because it depends on where the driver put the arena's physical pages
+    (profiles/layout_scan.py, profiles/r02/layout_scan*.txt: +3 x 2 MB was best in one process, +29 x 2 MB in another,
+    295-298 us against 317 us for the default spacing).  So it is measured: ONE arena is allocated; for every candidate
+    (slab spacing = minimal 2-MB-aligned slab + e x 2 MB, stagger s) the fields named in `order` are placed at
+    i x spacing + (i x s) mod 64 KB, `sources[name]` ([level][column] tensors, or None for outputs) are copied in and
+    `launch(fields)` - the caller's real kernel sequence on those fields - is timed with HIP events (median of `rounds` x
+    `launches`; `budget_s` caps the GPU time spent, so big fields try fewer candidates).  Returns (fields at the fastest placement, inputs copied in and outputs zeroed; a report dict).  Like
+    picking a ring depth by grid size, this decides nothing about the arithmetic; results are bit-identical."""
+    dt, dev = torch_dtype(dtype), torch.device(device)
+    item = torch.empty((), dtype=dt).element_size()
+    n = len(order)
+    two_mb = FieldArena.SLAB_ALIGN
+    slab = -(-((nz + 1) * nx * item + FieldArena.STAGGER_WRAP) // two_mb) * two_mb
+    emax = max(spacings)
+    buf = torch.zeros((n * (slab + emax * two_mb) + two_mb) // item, dtype=dt, device=dev)
+    base = (-buf.data_ptr()) % two_mb
+    count = (nz + 1) * nx
+
+    def place(e, st):
+        fields = {}
+        for i, name in enumerate(order):
+            o = (base + i * (slab + e * two_mb) + (i * st) % FieldArena.STAGGER_WRAP) // item
+            fields[name] = logical_view(buf[o:o + count].view(nz + 1, nx))
+        for name, src in sources.items():
+            if src is not None:
+                klayout(fields[name]).copy_(src)
+        return fields
+
+    def timed(fields):
+        for _ in range(2):
+            launch(fields)
+        ts = []
+        for _ in range(rounds):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(launches):
+                launch(fields)
+            b.record()
+            torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b) / launches)
+        return sorted(ts)[len(ts) // 2]
+
+    default = (min(spacings), staggers[0])
+    # steady state first.  After an idle period the GPU needs 10-15 ms of work to reach its core clocks
+    # (profiles/r02/window_probe.txt) and, on this pool, up to a second of sustained streaming before the memory side
+    # settles (the same placement measured at the start and at the end of an un-warmed calibration differed by 10 %):
+    # candidates timed during either ramp would lose to later ones for that reason alone.  So the default placement is
+    # run until two consecutive chunks agree to 1 % (at most ~1.5 s).
+    warm = place(*default)
+
+    def chunk_ms(nl_):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(nl_):
+            launch(warm)
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / nl_
+
+    t1 = chunk_ms(1)
+    per_chunk = max(2, min(100, int(60.0 / max(t1, 1e-3))))      # ~60 ms of work per chunk
+    prev, spent = chunk_ms(per_chunk), 0.0
+    while spent < 1500.0:
+        cur = chunk_ms(per_chunk)
+        spent += cur * per_chunk
+        if abs(cur - prev) <= 0.01 * prev:
+            break
+        prev = cur
+    t_default = timed(warm)
+    results = [(t_default, default[0], default[1])]
+    cands = [(e, st) for e in spacings for st in staggers if (e, st) != default]
+    # as many candidates as fit `budget_s` of GPU time (big fields: fewer), spread evenly over the list
+    per_cand = (2 + rounds * launches) * t_default * 1e-3 * 1.3
+    keep = max(7, min(len(cands), int(budget_s / max(per_cand, 1e-6))))
+    if keep < len(cands):
+        cands = [cands[round(i * (len(cands) - 1) / (keep - 1))] for i in range(keep)]
+    for e, st in cands:
+        results.append((timed(place(e, st)), e, st))
+    t_best, e_best, st_best = min(results)
+    # second pass over the eight fastest (residual drift and single lucky measurements), then the winner against the
+    # default once more
+    finals = sorted((timed(place(e, st)), e, st) for _, e, st in sorted(results)[:8])
+    _, e_best, st_best = finals[0]
+    t_best2, t_default2 = timed(place(e_best, st_best)), timed(place(*default))
+    if t_best2 >= t_default2:
+        e_best, st_best, t_best2 = default[0], default[1], t_default2
+    fields = place(e_best, st_best)
+    for name in order:
+        if sources.get(name) is None:
+            fields[name].zero_()
+    report = {"candidates": len(results), "default_ms": t_default2, "tuned_ms": t_best2, "first_pass_default_ms": t_default,
+              "first_pass_best_ms": t_best, "extra_spacing_x2MB": int(e_best), "stagger_bytes": int(st_best),
+              "slab_bytes": int(slab), "arena_bytes": int(buf.numel() * item),
+              "first_pass_top": [(round(t, 4), e, st) for t, e, st in sorted(results)[:8]],
+              "second_pass": [(round(t, 4), e, st) for t, e, st in finals]}
+    return fields, report
+
+
+#: automatic arenas behind `zeros` / `from_klayout` for GPU fields: slabs per arena (0 = one torch allocation per field)
+_ARENA_CAPACITY = int(os.environ.get("CLOUDSC2_FIELD_ARENA", "0"))
+_ARENA_MAX_BYTES = 48 << 30       # an automatic arena never exceeds this; bigger fields get fewer slabs per arena
+_arenas: Dict[Tuple[int, int, torch.dtype, torch.device], FieldArena] = {}
+
+
+def set_arena_capacity(capacity: int) -> int:
+    """Slabs per automatic arena (0 disables arenas); returns the previous setting.  Existing fields are unaffected."""
+    global _ARENA_CAPACITY
+    old, _ARENA_CAPACITY = _ARENA_CAPACITY, int(capacity)
+    _arenas.clear()
+    return old
+
+
+def _arena_for(nx: int, nz: int, dtype: torch.dtype, device: torch.device) -> Optional[FieldArena]:
+    if _ARENA_CAPACITY <= 0 or device.type != "cuda" or nx <= 0:
+        return None
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    key = (nx, nz, dtype, device)
+    a = _arenas.get(key)
+    if a is None or a.free_slots == 0:
+        item = torch.empty((), dtype=dtype).element_size()
+        slab = -(-((nz + 1) * nx * item + FieldArena.STAGGER_WRAP) // FieldArena.SLAB_ALIGN) * FieldArena.SLAB_ALIGN
+        cap = max(1, min(_ARENA_CAPACITY, _ARENA_MAX_BYTES // slab))
+        a = _arenas[key] = FieldArena(nx, nz, dtype, device, cap)
+    return a
+
+
 def zeros(nx: int, nz: int, dtype: Any, device: Any) -> torch.Tensor:
-    """Zero-initialised 3-D field, logical shape (nx, 1, nz+1)."""
-    return logical_view(torch.zeros((nz + 1, nx), dtype=torch_dtype(dtype), device=device))
+    """Zero-initialised 3-D field, logical shape (nx, 1, nz+1); on the GPU a slab of an automatic `FieldArena`."""
+    dt, dev = torch_dtype(dtype), torch.device(device)
+    arena = _arena_for(int(nx), int(nz), dt, dev) if dt.is_floating_point else None
+    if arena is not None:
+        return arena.zeros()
+    return logical_view(torch.zeros((nz + 1, nx), dtype=dt, device=dev))
 
 
 def zeros_k(nz: int, dtype: Any, device: Any) -> torch.Tensor:
@@ -58,7 +248,14 @@ def zeros_k(nz: int, dtype: Any, device: Any) -> torch.Tensor:
 def from_klayout(array_kc: Any, dtype: Any, device: Any) -> torch.Tensor:
     """Copy a host/device ``[level][column]`` array into a new field storage."""
     t = torch.as_tensor(array_kc)
-    t = t.to(device=device, dtype=torch_dtype(dtype)).contiguous()
+    dt, dev = torch_dtype(dtype), torch.device(device)
+    if t.dim() == 2 and dt.is_floating_point:
+        arena = _arena_for(int(t.shape[1]), int(t.shape[0]) - 1, dt, dev)
+        if arena is not None:
+            f = arena.zeros()
+            klayout(f).copy_(t)
+            return f
+    t = t.to(device=dev, dtype=dt).contiguous()
     return logical_view(t)
 
 

@@ -60,21 +60,36 @@ def main():
     item = np.dtype(np_dtype).itemsize
 
     def make_set(layout):
-        if layout == "separate":
+        layout = layout.split("#")[0]        # "name#tag": the tag only makes repeated layouts distinct sets
+        if layout.startswith("separate"):
+            # "separate[:<stagger>]": one torch allocation per field, field i starting i * <stagger> bytes (mod 64 KB) into it
             ls = nx
-            Z = lambda: storage.zeros(nx, nz, np_dtype, dev)  # noqa: E731
+            sep_stagger = int(layout.split(":")[1]) if ":" in layout else 0
+            count = [0]
+
+            def Z():
+                i = count[0]
+                count[0] += 1
+                off = (i * sep_stagger) % 65536 // item
+                buf = torch.zeros((nz + 1) * nx + 65536 // item, dtype=storage.torch_dtype(np_dtype), device=dev)
+                return storage.logical_view(buf[off:off + (nz + 1) * nx].view(nz + 1, nx))
         else:
             parts = layout.split(":")
             stagger = int(parts[1]) if len(parts) > 1 else 0
             ls = nx + (int(parts[2]) if len(parts) > 2 else 0)
             slab = (nz + 1) * ls + stagger // item
+            if parts[0] == "arena2m":       # slabs start on 2 MB boundaries of the arena, + i * stagger (mod 64 KB) inside them;
+                two_mb = (2 << 20) // item  # "arena2m:<stagger>:<lspad>:<extra>": slab spacing + <extra> x 2 MB
+                slab = ((nz + 1) * ls + 65536 // item + two_mb - 1) // two_mb * two_mb
+                slab += (int(parts[3]) if len(parts) > 3 else 0) * two_mb
             big = torch.zeros(80 * slab, dtype=storage.torch_dtype(np_dtype), device=dev)
             count = [0]
 
             def Z():
                 i = count[0]
                 count[0] += 1
-                return storage.logical_view(big[i * slab:i * slab + (nz + 1) * ls].view(nz + 1, ls)[:, :nx])
+                o = i * slab + ((i * stagger) % 65536 // item if parts[0] == "arena2m" else 0)
+                return storage.logical_view(big[o:o + (nz + 1) * ls].view(nz + 1, ls)[:, :nx])
         f = {}
         for k, v in s.items():
             t = Z()

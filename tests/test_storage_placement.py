@@ -1,0 +1,70 @@
+"""`storage.FieldArena` / `storage.tune_placement`: WHERE the fields of a call sit in HBM.  Placement never
+changes results - the GPU test holds a tuned placement bit-equal to separately allocated fields - only how the 26+ concurrent
+streams of a call fall onto HBM channels and banks."""
+import numpy as np
+import pytest
+
+
+def test_field_arena_geometry_on_the_host():
+    import torch
+
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd import storage
+
+    a = storage.FieldArena(100, 137, np.float64, "cpu", capacity=5)
+    fields = [a.zeros() for _ in range(5)]
+    assert a.free_slots == 0
+    with pytest.raises(RuntimeError, match="full"):
+        a.zeros()
+    two_mb = 2 << 20
+    for i, f in enumerate(fields):
+        assert f.shape == (100, 1, 138) and storage.field_geometry(f) == (100, 138, 100)
+        assert f.data_ptr() % two_mb == (i * 2304) % 65536          # 2 MB slab start + i x 2 304 B stagger
+        assert float(f.abs().sum()) == 0.0
+    assert fields[1].data_ptr() - fields[0].data_ptr() == a.slab + 2304 and a.slab % two_mb == 0
+    fields[0].fill_(1.0)
+    assert float(fields[1].abs().sum()) == 0.0                      # slabs do not overlap
+    with pytest.raises(ValueError, match="multiple of 16"):
+        storage.FieldArena(8, 4, np.float64, "cpu", capacity=2, stagger=100)
+    # automatic arenas are off by default and never used for host fields
+    assert storage._ARENA_CAPACITY == 0 or storage._arena_for(8, 4, torch.float64, torch.device("cpu")) is None
+
+
+@pytest.mark.gpu
+def test_tuned_placement_is_bit_identical_and_reports_what_it_did(gpu):
+    import torch
+
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd import storage
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.stencils import NL_IN, NL_OUT, compile_stencil
+    from helpers import externals, nl_case
+
+    nx, nz = 2048, 137
+    ext = externals()
+    fields, eta, dt = nl_case(nx, seed=3)
+    eta_d = torch.as_tensor(eta, device=gpu)
+    sat = compile_stencil("saturation", ext)
+    nl = compile_stencil("cloudsc2_nl", ext)
+    com = dict(origin=(0, 0, 0), validate_args=True, exec_info=None)
+
+    def step(F):
+        sat(in_ap=F["in_ap"], in_t=F["in_t"], out_qsat=F["in_qsat"], domain=(nx, 1, nz), **com)
+        nl(**F, in_eta=eta_d, dt=dt, domain=(nx, 1, nz + 1), **com)
+
+    order = ["in_" + n for n in NL_IN] + ["out_" + n for n in NL_OUT]
+    sources = {k: torch.as_tensor(v, device=gpu) for k, v in fields.items() if k != "in_qsat"}
+    tuned, rep = storage.tune_placement(nx, nz, np.float64, gpu, order, sources, step, spacings=(0, 1, 2, 3),
+                                        staggers=(2304, 8448), budget_s=0.5)
+    assert rep["candidates"] >= 7 and rep["tuned_ms"] <= rep["default_ms"] and rep["stagger_bytes"] in (2304, 8448)
+    assert set(tuned) == set(order)
+    for k, src in sources.items():
+        assert torch.equal(storage.klayout(tuned[k]), src), k                       # inputs copied in
+    ptrs = sorted(t.data_ptr() for t in tuned.values())
+    assert all(b - a >= (nz + 1) * nx * 8 for a, b in zip(ptrs, ptrs[1:]))           # disjoint slabs
+    step(tuned)
+    sep = {k: storage.from_klayout(v, np.float64, gpu) for k, v in sources.items()}
+    sep["in_qsat"] = storage.zeros(nx, nz, np.float64, gpu)
+    sep.update({"out_" + n: storage.zeros(nx, nz, np.float64, gpu) for n in NL_OUT})
+    step(sep)
+    torch.cuda.synchronize()
+    for n in NL_OUT:
+        assert torch.equal(tuned["out_" + n], sep["out_" + n]), n
+    assert torch.equal(tuned["in_qsat"], sep["in_qsat"])

@@ -375,7 +375,14 @@ def main(argv=None):
     s = make_resident_state(total, nz, rank * nx, nx, np_dtype, device)
     eta = torch.as_tensor(eta_levels(nz, dtype=np_dtype), device=device)  # from GLOBAL column 0
     sat = compile_stencil("saturation", ext)
-    nl = compile_stencil("cloudsc2_nl", ext)
+    _nl = compile_stencil("cloudsc2_nl", ext)
+    nl_launches = [0]        # cloudsc2_nl launches in this rank's working precision so far (the placement tuner's included):
+                             # lets a kernel trace of this command be cut to the launches of the event-timed pass
+
+    def nl(**kw):
+        if kw["in_ap"].dtype == storage.torch_dtype(np_dtype):
+            nl_launches[0] += 1
+        return _nl(**kw)
 
     def step_on(F):
         sat(in_ap=F["in_ap"], in_t=F["in_t"], out_qsat=F["in_qsat"], domain=(nx, 1, nz), **com)
@@ -448,7 +455,9 @@ def main(argv=None):
             step()                   # reach its steady clocks (profiles/r02/window_probe.txt); 20 steps were not enough
         nl_kernel_name = last_kernel()
         reps = max(10, min(args.steps, 50))
+        nl_window_first = nl_launches[0] + 2          # event_times discards its first two intervals
         nl_ms = event_times(nl_only, reps, before=sat_only)
+        nl_window = [nl_window_first, nl_launches[0] - 1]
         # the same kernel in a back-to-back train (no other kernel in between), for reference
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
@@ -630,7 +639,8 @@ def main(argv=None):
         res["validation_norm"] = dict(zip(NL_OUT, norm))
         if nl_ms is not None:
             res["roofline"] = roofline_entry(nl_kernel_name, NL_WORDS_PER_COL, wsize, nx, args.precision, nl_ms,
-                                             avg_launch_ms_back_to_back=nl_train_ms, box_copy_ceiling_GBs=copy_gbs)
+                                             avg_launch_ms_back_to_back=nl_train_ms, box_copy_ceiling_GBs=copy_gbs,
+                                             launch_window=nl_window)
         res.update(extra)
         if fused is not None:
             res["fused_step"] = fused

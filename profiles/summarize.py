@@ -55,6 +55,19 @@ for r in stats(f"gpurun_out/prof_{tag}/trace/*/*kernel_stats.csv", f"{out}/bench
     print("bench.py        :", r["Name"].split("(")[0][:56], r["Calls"], round(float(r["AverageNs"]) / 1e3, 1), "us")
 show(pmc(f"gpurun_out/prof_{tag}/pmc_*/*/*counter_collection.csv", f"{out}/nl_fp64_65536_pmc.json"))
 
+def window_average(trace_glob, first, last, needle):
+    """mean duration (us) of launches [first, last] (0-based, in time order) of the kernel whose name contains `needle`,
+    from the per-dispatch kernel trace - the launches bench.py's event-timed pass covers (`roofline.launch_window`)"""
+    rows = []
+    for f in glob.glob(trace_glob):
+        for r in csv.DictReader(open(f)):
+            if needle in r["Kernel_Name"]:
+                rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+    rows.sort()
+    sel = rows[first:last + 1]
+    return (sum(e - b for b, e in sel) / len(sel) / 1e3, len(sel), len(rows)) if sel else (None, 0, len(rows))
+
+
 # the bench line printed by the profiled run itself (pass 1), for the stats-vs-events comparison
 try:
     for line in open(f"gpurun_out/prof_{tag}/trace.log", errors="replace"):
@@ -65,5 +78,20 @@ try:
                 if k in d:
                     print(f"profiled run's own events: {k}: {d[k]['kernel']} avg_launch_ms {d[k]['avg_launch_ms']:.4f}")
             print("ms_per_step", d["ms_per_step"])
+            win = d["roofline"].get("launch_window")
+            if win:
+                prec = "double" if d["dtype"] == "f64" else "float"
+                avg, n, tot = window_average(f"gpurun_out/prof_{tag}/trace/*/*kernel_trace.csv", win[0], win[1],
+                                             f"nl_ring_kernel<{prec}")
+                if avg is None:
+                    avg, n, tot = window_average(f"gpurun_out/prof_{tag}/trace/*/*kernel_trace.csv", win[0], win[1],
+                                                 f"nl_kernel<{prec}")
+                # the fused-saturation instantiation (..., true>) is launched after the event pass, so an index window over
+                # all nl_ring_kernel<prec> launches in time order is the unfused ones of the pass
+                if avg is not None:
+                    msg = (f"kernel trace, launches {win[0]}..{win[1]} of {tot} ({n} launches = the event-timed pass): "
+                           f"{avg:.1f} us  vs events {d['roofline']['avg_launch_ms'] * 1e3:.1f} us")
+                    print(msg)
+                    open(f"{out}/bench_nl_event_window.txt", "w").write(msg + "\n")
 except OSError:
     pass

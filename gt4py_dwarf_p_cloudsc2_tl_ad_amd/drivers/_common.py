@@ -167,3 +167,43 @@ def init_distributed_from_env() -> None:
         local = int(os.environ.get("LOCAL_RANK", "0"))
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+
+def tune_field_placement(field_dicts, objective, **tuner_kw) -> Dict[str, Any]:
+    """Re-place every 3-D GPU field found in `field_dicts` (dicts name -> DataArray; a field shared by several dicts or
+    DataArrays is one field) at the placement `storage.tune_placement` measures to be fastest for `objective()` - the
+    caller's own timed region, run on the candidate placement.  Contents are preserved; the DataArrays are re-pointed at
+    the new storages in place, so every dict keeps working.  Returns the tuner's report."""
+    from ..framework.fields import FieldTensor
+
+    by_ptr: Dict[int, list] = {}
+    for d in field_dicts:
+        for v in d.values():
+            t = getattr(v, "data", None)
+            if isinstance(v, DataArray) and isinstance(t, torch.Tensor) and t.dim() == 3 and t.is_cuda and t.shape[1] == 1:
+                by_ptr.setdefault(t.data_ptr(), [])
+                if all(v is not w for w in by_ptr[t.data_ptr()]):
+                    by_ptr[t.data_ptr()].append(v)
+    if not by_ptr:
+        return {"fields": 0}
+    groups = list(by_ptr.values())
+    first = groups[0][0].data
+    nx, nz = first.shape[0], first.shape[2] - 1
+    if any(g[0].data.shape != first.shape or g[0].data.dtype != first.dtype for g in groups):
+        raise ValueError("tune_field_placement: the fields must share one shape and dtype")
+    order = [f"f{i}" for i in range(len(groups))]
+    sources = {n: storage.klayout(g[0].data.as_subclass(torch.Tensor)).clone() for n, g in zip(order, groups)}
+
+    def launch(fields):
+        for n, g in zip(order, groups):
+            for da in g:
+                da.data = fields[n].as_subclass(FieldTensor)
+        objective()
+
+    np_dtype = {torch.float64: np.float64, torch.float32: np.float32}[first.dtype]
+    fields, report = storage.tune_placement(nx, nz, np_dtype, first.device, order, sources, launch, **tuner_kw)
+    for n, g in zip(order, groups):
+        for da in g:
+            da.data = fields[n].as_subclass(FieldTensor)
+    report["fields"] = len(groups)
+    return report

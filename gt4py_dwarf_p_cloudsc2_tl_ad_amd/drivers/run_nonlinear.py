@@ -9,7 +9,7 @@ from ..framework.output import print_performance, write_performance_to_csv, writ
 from ..framework.timing import timing
 from ..framework.validation import validate
 from ..physics import Cloudsc2NL, Cloudsc2NLSaturation, Saturation
-from ._common import DATA_DIR, add_common_options, init_distributed_from_env, setup
+from ._common import DATA_DIR, add_common_options, init_distributed_from_env, setup, tune_field_placement
 
 
 def core(args):
@@ -32,6 +32,17 @@ def core(args):
             saturation(state, out=diags)
         cloudsc2_nl(state, dt, out_tendencies=tends, out_diagnostics=diags)
 
+    if args.tune_placement:
+        # build extension: where the ~26 fields of the timed region sit in HBM is measured and fixed for
+        # this process, with the timed region itself as the objective; contents and results are unchanged
+        saved = cfg.gt4py_config.exec_info
+        cfg.gt4py_config.exec_info = None
+        rep = tune_field_placement([state, diags, tends], one_run)
+        cfg.gt4py_config.exec_info = saved
+        ctx["placement"] = rep
+        print(f"[cloudsc2-hip] field placement tuned over {rep.get('candidates')} candidates: "
+              f"{rep.get('default_ms', 0):.4f} -> {rep.get('tuned_ms', 0):.4f} ms per run "
+              f"(+{rep.get('extra_spacing_x2MB')} x 2 MB slab spacing, stagger {rep.get('stagger_bytes')} B, {rep.get('fields')} fields)")
     graph = None
     if args.graph:
         # --graph: the timed region is captured ONCE into a HIP graph (torch.cuda.CUDAGraph on a side stream; the
@@ -111,6 +122,8 @@ def main(argv=None):
                     help="timed region as ONE launch: saturation fused into cloudsc2_nl (build extension)")
     ap.add_argument("--graph", action="store_true",
                     help="capture the timed region in a HIP graph and replay it (launch-bound loop -> one host call)")
+    ap.add_argument("--tune-placement", action="store_true",
+                    help="measure and fix the HBM placement of the timed region's fields for this process (storage.tune_placement)")
     ap.add_argument("--atol", type=float, default=None)
     ap.add_argument("--rtol", type=float, default=None)
     args = ap.parse_args(argv)

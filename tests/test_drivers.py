@@ -313,3 +313,22 @@ def test_eta_levels_on_the_device_match_the_oracle(gpu, precision, capsys):
         if source == "synthetic":
             assert np.array_equal(want, eta_levels(137, dtype=want.dtype))
     capsys.readouterr()
+
+
+@pytest.mark.gpu
+def test_nonlinear_driver_with_tuned_field_placement(gpu, capsys):
+    """`--tune-placement`: the driver's state, diagnostics and tendencies are re-placed in HBM (storage.tune_placement, the
+    timed region as the objective); the fields it ends with are those of the plain run, bit for bit."""
+    import torch
+
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.drivers import run_nonlinear
+
+    base = ["--backend", "hip", "--num-cols", "8192", "--num-runs", "3", "--disable-validation", "--input", "synthetic"]
+    a = run_nonlinear.main(base)
+    b = run_nonlinear.main(base + ["--tune-placement"])
+    out = capsys.readouterr().out
+    assert "field placement tuned over" in out and b["placement"]["fields"] >= 26
+    assert b["placement"]["tuned_ms"] <= b["placement"]["default_ms"]
+    for d in ("tends", "diags"):
+        for k, v in a[d].items():
+            assert torch.equal(v.data, b[d][k].data), k

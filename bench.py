@@ -22,6 +22,12 @@ plain `python bench.py` (no WORLD_SIZE in the environment), this process starts 
 with N ranks as a CHILD process - before torch is imported or any GPU call is made here - relays rank 0's JSON
 line and exits with the child's return code.
 
+Field placement: before anything is timed, `storage.tune_placement` measures where the 26 fields of the step should sit in
+HBM for this process (same kernels, same arguments, bit-identical results; the spacing between the fields' starting
+addresses decides how 26 concurrent streams fall onto HBM channels and banks, worth up to 10 %) and the
+state is placed there; `--placement separate` gives one torch allocation per field instead.  The record says what was done
+(`placement`).
+
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel of the step (the `cloudsc2_nl` kernel; its name
 is the one the launcher reports): algorithmic bytes per launch (3 567 words per column) / the kernel's
 mean duration measured with HIP events on the launch stream.  At N = 1 the line also carries `roofline_tl`,

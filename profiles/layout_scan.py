@@ -95,6 +95,14 @@ def main():
             for st in [int(x) for x in opts.get("staggers", "2304").split(",")]:
                 if sp * (1 << 20) >= fbytes + 65536:
                     cands[f"spacing {sp} MB stagger {st}"] = [i * sp * (1 << 20) + (i * st) % 65536 for i in range(nfields)]
+    if "random" in opts:         # --random=N: N placements with a random 256-B-granular offset (< 4 MB) per field on 76 MB slabs
+        rng = np.random.default_rng(int(opts.get("seed", 1)))
+        cands = {"slab2m stagger 0": cands["slab2m stagger 0"],
+                 "slab2m stagger 2304": [i * slab2m + (i * 2304) % 65536 for i in range(nfields)]}
+        for e in (61, 62):
+            cands[f"spacing +{e}x2MB stagger 2304"] = [i * (slab2m + e * two_mb) + (i * 2304) % 65536 for i in range(nfields)]
+        for j in range(int(opts["random"])):
+            cands[f"random #{j}"] = [i * (slab2m + 2 * two_mb) + int(rng.integers(0, 16384)) * 256 for i in range(nfields)]
     arena_need = max(max(v) for v in cands.values()) + fbytes + base0 + (1 << 20)
     if arena_need > arena_bytes:
         del arena

@@ -99,7 +99,8 @@ class FieldArena:
 
 
 def tune_placement(nx: int, nz: int, dtype: Any, device: Any, order, sources, launch, *, spacings=tuple(range(0, 64)),
-                   staggers=(FieldArena.STAGGER, 8448), launches: int = 5, rounds: int = 3, budget_s: float = 2.5):
+                   staggers=(FieldArena.STAGGER, 8448), shifts_mb=(0, 4096, 8192, 12288), launches: int = 5,
+                   rounds: int = 3, budget_s: float = 3.0, max_arena_bytes: int = 40 << 30):
     """Calibrate WHERE the fields of a stencil call sit in HBM, for this process.
 
     The rate at which a call streams its 26-72 fields depends on how their starting addresses relate (channel, bank and
@@ -107,8 +108,8 @@ def tune_placement(nx: int, nz: int, dtype: Any, device: Any, order, sources, la
     starts differs from process to process, because it depends on where the driver put the arena's physical pages
     (profiles/layout_scan.py, profiles/r02/layout_scan*.txt: +3 x 2 MB was best in one process, +29 x 2 MB in another,
     295-298 us against 317 us for the default spacing).  So it is measured: ONE arena is allocated; for every candidate
-    (slab spacing = minimal 2-MB-aligned slab + e x 2 MB, stagger s) the fields named in `order` are placed at
-    i x spacing + (i x s) mod 64 KB, `sources[name]` ([level][column] tensors, or None for outputs) are copied in and
+    (slab spacing = minimal 2-MB-aligned slab + e x 2 MB, stagger s, and a shift of the whole placement inside the arena)
+    the fields named in `order` are placed at shift + i x spacing + (i x s) mod 64 KB, `sources[name]` ([level][column] tensors, or None for outputs) are copied in and
     `launch(fields)` - the caller's real kernel sequence on those fields - is timed with HIP events (median of `rounds` x
     `launches`; `budget_s` caps the GPU time spent, so big fields try fewer candidates).  Returns (fields at the fastest placement, inputs copied in and outputs zeroed; a report dict).  Like
     picking a ring depth by grid size, this decides nothing about the arithmetic; results are bit-identical."""
@@ -118,14 +119,18 @@ def tune_placement(nx: int, nz: int, dtype: Any, device: Any, order, sources, la
     two_mb = FieldArena.SLAB_ALIGN
     slab = -(-((nz + 1) * nx * item + FieldArena.STAGGER_WRAP) // two_mb) * two_mb
     emax = max(spacings)
-    buf = torch.zeros((n * (slab + emax * two_mb) + two_mb) // item, dtype=dt, device=dev)
+    span = n * (slab + emax * two_mb) + two_mb
+    # the same relative placement also differs by WHERE in the allocation it sits (profiles/r02/layout_scan.txt, "shifted"):
+    # a few whole-placement shifts are candidates too, as far as the arena may grow
+    shifts = [int(sh) << 20 for sh in shifts_mb if span + (int(sh) << 20) <= max_arena_bytes and (int(sh) << 20) <= 4 * span] or [0]
+    buf = torch.zeros((span + max(shifts)) // item, dtype=dt, device=dev)
     base = (-buf.data_ptr()) % two_mb
     count = (nz + 1) * nx
 
-    def place(e, st):
+    def place(e, st, sh=0):
         fields = {}
         for i, name in enumerate(order):
-            o = (base + i * (slab + e * two_mb) + (i * st) % FieldArena.STAGGER_WRAP) // item
+            o = (base + sh + i * (slab + e * two_mb) + (i * st) % FieldArena.STAGGER_WRAP) // item
             fields[name] = logical_view(buf[o:o + count].view(nz + 1, nx))
         for name, src in sources.items():
             if src is not None:
@@ -173,32 +178,36 @@ def tune_placement(nx: int, nz: int, dtype: Any, device: Any, order, sources, la
             break
         prev = cur
     t_default = timed(warm)
-    results = [(t_default, default[0], default[1])]
-    cands = [(e, st) for e in spacings for st in staggers if (e, st) != default]
+    default = (default[0], default[1], 0)
+    results = [(t_default,) + default]
+    cands = [(e, st, 0) for e in spacings for st in staggers if (e, st, 0) != default]
+    probe = sorted({min(spacings), emax // 2, emax - 3, emax - 2, emax - 1, emax} & set(spacings))
+    cands += [(e, st, sh) for sh in shifts[1:] for e in probe for st in staggers]
     # as many candidates as fit `budget_s` of GPU time (big fields: fewer), spread evenly over the list
     per_cand = (2 + rounds * launches) * t_default * 1e-3 * 1.3
     keep = max(7, min(len(cands), int(budget_s / max(per_cand, 1e-6))))
     if keep < len(cands):
         cands = [cands[round(i * (len(cands) - 1) / (keep - 1))] for i in range(keep)]
-    for e, st in cands:
-        results.append((timed(place(e, st)), e, st))
-    t_best, e_best, st_best = min(results)
+    for c in cands:
+        results.append((timed(place(*c)),) + c)
+    t_best = min(results)[0]
     # second pass over the eight fastest (residual drift and single lucky measurements), then the winner against the
     # default once more
-    finals = sorted((timed(place(e, st)), e, st) for _, e, st in sorted(results)[:8])
-    _, e_best, st_best = finals[0]
-    t_best2, t_default2 = timed(place(e_best, st_best)), timed(place(*default))
+    finals = sorted((timed(place(*c[1:])),) + c[1:] for c in sorted(results)[:8])
+    best = finals[0][1:]
+    t_best2, t_default2 = timed(place(*best)), timed(place(*default))
     if t_best2 >= t_default2:
-        e_best, st_best, t_best2 = default[0], default[1], t_default2
-    fields = place(e_best, st_best)
+        best, t_best2 = default, t_default2
+    e_best, st_best, sh_best = best
+    fields = place(*best)
     for name in order:
         if sources.get(name) is None:
             fields[name].zero_()
     report = {"candidates": len(results), "default_ms": t_default2, "tuned_ms": t_best2, "first_pass_default_ms": t_default,
-              "first_pass_best_ms": t_best, "extra_spacing_x2MB": int(e_best), "stagger_bytes": int(st_best),
+              "first_pass_best_ms": t_best, "extra_spacing_x2MB": int(e_best), "stagger_bytes": int(st_best), "shift_MB": int(sh_best >> 20),
               "slab_bytes": int(slab), "arena_bytes": int(buf.numel() * item),
-              "first_pass_top": [(round(t, 4), e, st) for t, e, st in sorted(results)[:8]],
-              "second_pass": [(round(t, 4), e, st) for t, e, st in finals]}
+              "first_pass_top": [(round(c[0], 4), c[1], c[2], c[3] >> 20) for c in sorted(results)[:8]],
+              "second_pass": [(round(c[0], 4), c[1], c[2], c[3] >> 20) for c in finals]}
     return fields, report
 
 

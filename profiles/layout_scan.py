@@ -95,6 +95,13 @@ def main():
             for st in [int(x) for x in opts.get("staggers", "2304").split(",")]:
                 if sp * (1 << 20) >= fbytes + 65536:
                     cands[f"spacing {sp} MB stagger {st}"] = [i * sp * (1 << 20) + (i * st) % 65536 for i in range(nfields)]
+    if "shifts" in opts:         # --shifts=a,b,... (MB): the SAME relative placement (2-MB slabs, stagger 2304) moved through the arena
+        rel = [i * slab2m + (i * 2304) % 65536 for i in range(nfields)]
+        rel192 = [i * 192 * (1 << 20) + (i * 2304) % 65536 for i in range(nfields)]
+        cands = {"slab2m stagger 0": cands["slab2m stagger 0"]}
+        for sh in [int(x) for x in opts["shifts"].split(",")]:
+            cands[f"dense (70 MB) shifted by {sh} MB"] = [o + sh * (1 << 20) for o in rel]
+            cands[f"192 MB spacing shifted by {sh} MB"] = [o + sh * (1 << 20) for o in rel192]
     if "random" in opts:         # --random=N: N placements with a random 256-B-granular offset (< 4 MB) per field on 76 MB slabs
         rng = np.random.default_rng(int(opts.get("seed", 1)))
         cands = {"slab2m stagger 0": cands["slab2m stagger 0"],

@@ -565,15 +565,6 @@ def main(argv=None):
             torch.cuda.empty_cache()
             return out
 
-        # ---- the other kernels of the path, each against its own roofline (N = 1, headline configuration only).  A failure
-        # here (e.g. out of memory on a shared device) must not cost the headline line: it is recorded and the run goes on.
-        if world == 1 and not args.no_extra_rooflines and args.config == 2 and nx <= 131072:
-            try:
-                extra.update(extra_rooflines())
-            except Exception as exc:  # noqa: BLE001
-                extra["extra_rooflines_error"] = f"{type(exc).__name__}: {exc}"
-                torch.cuda.empty_cache()
-
     # ---- the timed region: W warm-up steps, then EXACTLY K steps between barrier + synchronize pairs.
     # Clock state: this GPU runs the step ~12 % slower (0.425 vs 0.375 ms) for the first ~10-15 ms of work that follows
     # an idle period of >= ~50 ms, whatever caused it - a garbage collection, an allocation, the host building the next
@@ -626,6 +617,18 @@ def main(argv=None):
                  "kernel": last_kernel(), "results_equal_unfused": same,
                  "what": "saturation + cloudsc2_nl as one launch (cloudsc2_nl_fused_*)"}
         del qsat2, outs2
+
+    # ---- the other kernels of the path, each against its own roofline (N = 1, headline configuration only), AFTER the
+    # timed window: their tuning runs other sizes and frees GBs of arenas, and a 20-step window that followed them was
+    # 2 % slower than one that did not (profiles/r02/window_vs_extras.txt).  A failure here (e.g. out of memory on a
+    # shared device) must not cost the headline line: it is recorded and the run goes on.
+    if (not args.no_roofline_events and world == 1 and not args.no_extra_rooflines and args.config == 2
+            and nx <= 131072):
+        try:
+            extra.update(extra_rooflines())
+        except Exception as exc:  # noqa: BLE001
+            extra["extra_rooflines_error"] = f"{type(exc).__name__}: {exc}"
+            torch.cuda.empty_cache()
 
     # validation norm (the only data reduction across ranks): sum of every NL output
     norm = torch.stack([storage.klayout(outs["out_" + n]).double().abs().sum() for n in NL_OUT])

@@ -100,7 +100,7 @@ class FieldArena:
 
 def tune_placement(nx: int, nz: int, dtype: Any, device: Any, order, sources, launch, *, spacings=tuple(range(0, 64)),
                    staggers=(FieldArena.STAGGER, 8448), shifts_mb=(0, 4096, 8192, 12288), launches: int = 5,
-                   rounds: int = 3, budget_s: float = 3.0, max_arena_bytes: int = 40 << 30):
+                   rounds: int = 3, budget_s: float = 4.0, max_arena_bytes: int = 40 << 30):
     """Calibrate WHERE the fields of a stencil call sit in HBM, for this process.
 
     The rate at which a call streams its 26-72 fields depends on how their starting addresses relate (channel, bank and
@@ -181,8 +181,7 @@ def tune_placement(nx: int, nz: int, dtype: Any, device: Any, order, sources, la
     default = (default[0], default[1], 0)
     results = [(t_default,) + default]
     cands = [(e, st, 0) for e in spacings for st in staggers if (e, st, 0) != default]
-    probe = sorted({min(spacings), emax // 2, emax - 3, emax - 2, emax - 1, emax} & set(spacings))
-    cands += [(e, st, sh) for sh in shifts[1:] for e in probe for st in staggers]
+    cands += [(e, st, sh) for sh in shifts[1:] for e in spacings for st in staggers]
     # as many candidates as fit `budget_s` of GPU time (big fields: fewer), spread evenly over the list
     per_cand = (2 + rounds * launches) * t_default * 1e-3 * 1.3
     keep = max(7, min(len(cands), int(budget_s / max(per_cand, 1e-6))))

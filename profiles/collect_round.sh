@@ -13,3 +13,5 @@ bash profiles/run_rocprof_all.sh $TAG 65536 double >> $D/rocprof.log 2>&1
 bash profiles/run_rocprof_all.sh $TAG 524288 single >> $D/rocprof.log 2>&1
 python profiles/summarize.py $TAG $D/summary > $D/summary.txt 2>&1
 tail -40 $D/summary.txt
+# the raw rocprofv3 output (>100 MB of CSV) stays on the box unless KEEP_RAW=1: gpurun merges back at most 64 MiB
+[ -n "$KEEP_RAW" ] || rm -rf gpurun_out/prof_${TAG} gpurun_out/prof_all_${TAG}_*

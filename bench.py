@@ -128,12 +128,15 @@ def launch_ranks(args, argv) -> int:
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
-def cpu_baseline(cols: int, nz: int, np_dtype, budget_s: float = 8.0):
+def cpu_baseline(cols: int, nz: int, np_dtype, budget_s: float = 8.0, hip_step=None):
     """CPU baselines on the host, saturation + cloudsc2_nl on `cols` synthetic columns (BASELINE configs[0] size):
       * headline `value`: the plain-C + OpenMP restatement (oracle/cloudsc2_nl_omp.c, SURVEY 8d "restatement B")
         on the host cores of this GPU's share, fp64, repeated for ~`budget_s` s;
       * `numpy_1core`: the NumPy restatement (GT4Py-numpy-like execution shape, single-threaded) for ~6 s.
-    Both are the checker (pinned to the executed reference source by tests/), timed here only as baselines."""
+    Both are the checker (pinned to the executed reference source by tests/), timed here only as baselines.
+    `hip_step(fields, eta, dt)` (the product path on the device, given by main()) is run on the SAME columns and held to
+    the C restatement's outputs with the parity tests' fp64 tolerance (tests/helpers.py: |a-b| <= 1e-9 |b| + 1e-11 max|b|);
+    the outcome goes into the record as `cpu_baseline.parity_check` - the checker checking, nothing it returns is shipped."""
     import numpy as np
 
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -176,6 +179,21 @@ def cpu_baseline(cols: int, nz: int, np_dtype, budget_s: float = 8.0):
             cloudsc2_c.cloudsc2_nl(F, eta, dt, ext, nthreads=threads)
 
         c_runs, c_el = loop(c_step, budget_s)
+        if hip_step is not None:
+            from helpers import TOL
+            tol = TOL[np.dtype("float64")]
+            got = hip_step(F, eta, dt)
+            worst, bad = 0.0, 0
+            for n in ("qsat",) + tuple(NL_OUT):
+                want = F["in_qsat"] if n == "qsat" else F["out_" + n]
+                scale = float(np.max(np.abs(want)))
+                err = np.abs(got[n] - want)
+                bad += int((err > tol["rtol"] * np.abs(want) + tol["atol_rel"] * scale).sum()) + int(np.isnan(got[n]).sum())
+                worst = max(worst, float(err.max() / scale) if scale > 0 else 0.0)
+            res["parity_check"] = {"columns": cols, "fields": 1 + len(NL_OUT), "points_outside_tolerance": bad,
+                                   "max_err_over_field_scale": worst, "rtol": tol["rtol"], "atol_rel": tol["atol_rel"],
+                                   "passed": bad == 0,
+                                   "what": "HIP saturation + cloudsc2_nl against oracle/cloudsc2_nl_omp.c on the same columns"}
         res.update(value=cols * c_runs / c_el, cores=threads,
                    sample=f"plain-C + OpenMP restatement (oracle/cloudsc2_nl_omp.c, {threads} threads, scalar libm, "
                           f"-O2), {what} float64, {c_runs} runs in {c_el:.1f} s, synthetic-parameters")
@@ -654,7 +672,25 @@ def main(argv=None):
         if fused is not None:
             res["fused_step"] = fused
         if world == 1 and args.cpu_cols > 0:
-            res["cpu_baseline"] = cpu_baseline(args.cpu_cols, nz, np.float64)
+            def hip_step(Fh, eta_h, dt_h):
+                """saturation + cloudsc2_nl through the stencil objects on host fields in [k][col] layout (fp64)"""
+                n_c = Fh["in_ap"].shape[1]
+                D = {k: storage.from_klayout(np.ascontiguousarray(v), np.float64, device) for k, v in Fh.items()
+                     if k.startswith("in_")}
+                D["in_qsat"] = storage.zeros(n_c, nz, np.float64, device)
+                O = {"out_" + n: storage.zeros(n_c, nz, np.float64, device) for n in NL_OUT}
+                s64 = compile_stencil("saturation", ext)
+                n64 = compile_stencil("cloudsc2_nl", ext)
+                s64(in_ap=D["in_ap"], in_t=D["in_t"], out_qsat=D["in_qsat"], domain=(n_c, 1, nz), **com)
+                n64(**D, **O, in_eta=torch.as_tensor(np.asarray(eta_h, dtype=np.float64), device=device), dt=dt_h,
+                    domain=(n_c, 1, nz + 1), **com)
+                torch.cuda.synchronize()
+                got = {n: storage.klayout(O["out_" + n]).cpu().numpy() for n in NL_OUT}
+                got["qsat"] = storage.klayout(D["in_qsat"]).cpu().numpy()
+                return got
+
+            res["cpu_baseline"] = cpu_baseline(args.cpu_cols, nz, np.float64,
+                                               hip_step=hip_step)
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -97,4 +97,7 @@ def test_bench_line_carries_the_contract_on_the_gpu(gpu):
         assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["kernel"].startswith("cs2::")
     assert d["roofline"]["kernel"] == "cs2::nl_ring_kernel" and d["roofline_tl"]["kernel"] == "cs2::tl_kernel"
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
+    pc = d["cpu_baseline"]["parity_check"]       # the HIP step on the baseline's own columns, held to the C restatement
+    assert pc["passed"] and pc["points_outside_tolerance"] == 0 and pc["columns"] == 256 and pc["fields"] == 11
+    assert 0 <= pc["max_err_over_field_scale"] < 1e-10
     assert d["fused_step"]["results_equal_unfused"] is True

@@ -108,11 +108,15 @@ def tune_placement(nx: int, nz: int, dtype: Any, device: Any, order, sources, la
     starts differs from process to process, because it depends on where the driver put the arena's physical pages
     (profiles/layout_scan.py, profiles/r02/layout_scan*.txt: +3 x 2 MB was best in one process, +29 x 2 MB in another,
     295-298 us against 317 us for the default spacing).  So it is measured: ONE arena is allocated; for every candidate
-    (slab spacing = minimal 2-MB-aligned slab + e x 2 MB, stagger s, and a shift of the whole placement inside the arena)
-    the fields named in `order` are placed at shift + i x spacing + (i x s) mod 64 KB, `sources[name]` ([level][column] tensors, or None for outputs) are copied in and
-    `launch(fields)` - the caller's real kernel sequence on those fields - is timed with HIP events (median of `rounds` x
-    `launches`; `budget_s` caps the GPU time spent, so big fields try fewer candidates).  Returns (fields at the fastest placement, inputs copied in and outputs zeroed; a report dict).  Like
-    picking a ring depth by grid size, this decides nothing about the arithmetic; results are bit-identical."""
+    (slab spacing = minimal 2-MB-aligned slab + e x 2 MB, stagger s, and a shift of the whole placement inside the
+    arena) the fields named in `order` are placed at shift + i x spacing + (i x s) mod 64 KB, `sources[name]`
+    ([level][column] tensors, or None for outputs) are copied in and `launch(fields)` - the caller's real kernel
+    sequence on those fields - is timed with HIP events (median of `rounds` x `launches`; `budget_s` caps the GPU time
+    spent, so slow sequences and big fields try an evenly spread subset of the candidates).
+
+    Returns (fields at the fastest placement - inputs copied in, outputs zeroed; a report dict).  The arena stays alive
+    as long as the returned fields do (up to `max_arena_bytes`, typically 17-23 GB of the 288 GB).  Like picking a ring
+    depth by grid size, this decides nothing about the arithmetic: results are bit-identical for every placement."""
     dt, dev = torch_dtype(dtype), torch.device(device)
     item = torch.empty((), dtype=dt).element_size()
     n = len(order)
@@ -122,7 +126,8 @@ def tune_placement(nx: int, nz: int, dtype: Any, device: Any, order, sources, la
     span = n * (slab + emax * two_mb) + two_mb
     # the same relative placement also differs by WHERE in the allocation it sits (profiles/r02/layout_scan.txt, "shifted"):
     # a few whole-placement shifts are candidates too, as far as the arena may grow
-    shifts = [int(sh) << 20 for sh in shifts_mb if span + (int(sh) << 20) <= max_arena_bytes and (int(sh) << 20) <= 4 * span] or [0]
+    shifts = [int(sh) << 20 for sh in shifts_mb
+              if span + (int(sh) << 20) <= max_arena_bytes and (int(sh) << 20) <= 4 * span] or [0]
     buf = torch.zeros((span + max(shifts)) // item, dtype=dt, device=dev)
     base = (-buf.data_ptr()) % two_mb
     count = (nz + 1) * nx
@@ -202,8 +207,9 @@ def tune_placement(nx: int, nz: int, dtype: Any, device: Any, order, sources, la
     for name in order:
         if sources.get(name) is None:
             fields[name].zero_()
-    report = {"candidates": len(results), "default_ms": t_default2, "tuned_ms": t_best2, "first_pass_default_ms": t_default,
-              "first_pass_best_ms": t_best, "extra_spacing_x2MB": int(e_best), "stagger_bytes": int(st_best), "shift_MB": int(sh_best >> 20),
+    report = {"candidates": len(results), "default_ms": t_default2, "tuned_ms": t_best2,
+              "first_pass_default_ms": t_default, "first_pass_best_ms": t_best,
+              "extra_spacing_x2MB": int(e_best), "stagger_bytes": int(st_best), "shift_MB": int(sh_best >> 20),
               "slab_bytes": int(slab), "arena_bytes": int(buf.numel() * item),
               "first_pass_top": [(round(c[0], 4), c[1], c[2], c[3] >> 20) for c in sorted(results)[:8]],
               "second_pass": [(round(c[0], 4), c[1], c[2], c[3] >> 20) for c in finals]}

@@ -418,11 +418,16 @@ def main(argv=None):
     order = ["in_" + n for n in NL_IN] + ["out_" + n for n in NL_OUT]
     sources = {"in_" + k[2:]: v for k, v in s.items()}
     placement = {"mode": args.placement}
+    F = None
     if args.placement == "tuned":
-        F, rep = storage.tune_placement(nx, nz, np_dtype, device, order, sources, step_on)
-        placement.update(rep)
-    else:
-        old_cap = storage.set_arena_capacity(32 if args.placement == "arena" else 0)
+        try:
+            F, rep = storage.tune_placement(nx, nz, np_dtype, device, order, sources, step_on)
+            placement.update(rep)
+        except RuntimeError as exc:      # e.g. a shared device without room for the arena: say so, run on plain allocations
+            placement = {"mode": "separate", "tune_error": f"{type(exc).__name__}: {exc}"[:300]}
+            torch.cuda.empty_cache()
+    if F is None:
+        old_cap = storage.set_arena_capacity(32 if placement["mode"] == "arena" else 0)
         F = {k: storage.from_klayout(v, np_dtype, device) for k, v in sources.items()}
         F["in_qsat"] = storage.zeros(nx, nz, np_dtype, device)
         F.update({"out_" + n: storage.zeros(nx, nz, np_dtype, device) for n in NL_OUT})

@@ -122,6 +122,12 @@ def tune_placement(nx: int, nz: int, dtype: Any, device: Any, order, sources, la
     n = len(order)
     two_mb = FieldArena.SLAB_ALIGN
     slab = -(-((nz + 1) * nx * item + FieldArena.STAGGER_WRAP) // two_mb) * two_mb
+    if dev.type == "cuda":       # never ask for more than 60 % of what is free now: fewer shifts, then narrower spacings
+        max_arena_bytes = min(max_arena_bytes, int(0.6 * torch.cuda.mem_get_info(dev)[0]))
+        fit = [e for e in spacings if n * (slab + e * two_mb) + two_mb <= int(0.6 * torch.cuda.mem_get_info(dev)[0])]
+        if not fit:
+            raise RuntimeError(f"tune_placement: {n} fields of {slab} B do not fit 60 % of the free device memory")
+        spacings = tuple(fit)
     emax = max(spacings)
     span = n * (slab + emax * two_mb) + two_mb
     # the same relative placement also differs by WHERE in the allocation it sits (profiles/r02/layout_scan.txt, "shifted"):

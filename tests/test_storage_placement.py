@@ -68,3 +68,28 @@ def test_tuned_placement_is_bit_identical_and_reports_what_it_did(gpu):
     for n in NL_OUT:
         assert torch.equal(tuned["out_" + n], sep["out_" + n]), n
     assert torch.equal(tuned["in_qsat"], sep["in_qsat"])
+
+
+@pytest.mark.gpu
+def test_tuner_sizes_its_arena_to_the_free_memory(gpu, monkeypatch):
+    """A shared or nearly full device: the tuner asks for at most 60 % of what is free (fewer shifts, narrower spacings)
+    and says so clearly when even the densest placement does not fit - bench.py then runs on plain allocations."""
+    import torch
+
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd import storage
+
+    nx, nz, order = 1024, 15, ["a", "b", "c"]
+    src = {"a": torch.ones(nz + 1, nx, dtype=torch.float64, device=gpu), "b": None, "c": None}
+
+    def launch(F):
+        F["c"].copy_(F["a"])
+
+    slab = 2 << 20                                   # one 2-MB slab per field at this size
+    real = torch.cuda.mem_get_info(gpu)
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda dev=None: (int((3 * (slab + 2 * slab) + slab) / 0.6) + 1, real[1]))
+    F, rep = storage.tune_placement(nx, nz, np.float64, gpu, order, src, launch, budget_s=0.2)
+    assert rep["extra_spacing_x2MB"] <= 2 and rep["shift_MB"] == 0 and rep["arena_bytes"] <= 3 * 3 * slab + slab
+    assert torch.equal(storage.klayout(F["a"]), src["a"]) and float(F["c"].abs().sum()) == 0.0
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda dev=None: (slab, real[1]))
+    with pytest.raises(RuntimeError, match="do not fit"):
+        storage.tune_placement(nx, nz, np.float64, gpu, order, src, launch, budget_s=0.2)

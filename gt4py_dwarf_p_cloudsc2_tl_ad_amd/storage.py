@@ -99,8 +99,10 @@ class FieldArena:
 
 
 def tune_placement(nx: int, nz: int, dtype: Any, device: Any, order, sources, launch, *, spacings=tuple(range(0, 64)),
-                   staggers=(FieldArena.STAGGER, 8448), shifts_mb=(0, 4096, 8192, 12288), launches: int = 5,
-                   rounds: int = 3, budget_s: float = 4.0, max_arena_bytes: int = 40 << 30):
+                   staggers=(FieldArena.STAGGER, 8448), shifts_mb=(0, 4096, 8192, 12288), wide_spacings=(),
+                   wide_shifts_mb=tuple(range(0, 32769, 2048)), launches: int = 5, rounds: int = 3,
+                   budget_s: float = 4.0, max_arena_bytes: int = 40 << 30, max_shift_spans: float = 4.0,
+                   keep_all: bool = False):
     """Calibrate WHERE the fields of a stencil call sit in HBM, for this process.
 
     The rate at which a call streams its 26-72 fields depends on how their starting addresses relate (channel, bank and
@@ -114,27 +116,37 @@ def tune_placement(nx: int, nz: int, dtype: Any, device: Any, order, sources, la
     sequence on those fields - is timed with HIP events (median of `rounds` x `launches`; `budget_s` caps the GPU time
     spent, so slow sequences and big fields try an evenly spread subset of the candidates).
 
+    Candidates: the full grid `spacings` x `staggers` x `shifts_mb` (whole-placement shifts, as far as the arena may
+    grow) and, when `wide_spacings` is given, a second family with 0.25-1 GB between field starts at every shift of
+    `wide_shifts_mb`.  The wide family is OFF by default: the speed of a placement has a ~32 GB period in the arena
+    offset on some leases (placements that straddle such a boundary with their last few fields beyond it run the NL
+    kernel 4-8 % faster, profiles/r02/placement_structure.txt) and a wide placement meets a boundary more often than a
+    narrow one - but over fresh processes it did not find faster placements than the narrow grid (same file, A/B).
+
     Returns (fields at the fastest placement - inputs copied in, outputs zeroed; a report dict).  The arena stays alive
-    as long as the returned fields do (up to `max_arena_bytes`, typically 17-23 GB of the 288 GB).  Like picking a ring
-    depth by grid size, this decides nothing about the arithmetic: results are bit-identical for every placement."""
+    as long as the returned fields do (up to `max_arena_bytes` and never more than 60 % of the free device memory:
+    typically 17-23 GB of the 288 GB).  Like picking a ring depth by grid size, this decides nothing about the
+    arithmetic: results are bit-identical for every placement."""
     dt, dev = torch_dtype(dtype), torch.device(device)
     item = torch.empty((), dtype=dt).element_size()
     n = len(order)
     two_mb = FieldArena.SLAB_ALIGN
     slab = -(-((nz + 1) * nx * item + FieldArena.STAGGER_WRAP) // two_mb) * two_mb
-    if dev.type == "cuda":       # never ask for more than 60 % of what is free now: fewer shifts, then narrower spacings
-        max_arena_bytes = min(max_arena_bytes, int(0.6 * torch.cuda.mem_get_info(dev)[0]))
-        fit = [e for e in spacings if n * (slab + e * two_mb) + two_mb <= int(0.6 * torch.cuda.mem_get_info(dev)[0])]
-        if not fit:
-            raise RuntimeError(f"tune_placement: {n} fields of {slab} B do not fit 60 % of the free device memory")
-        spacings = tuple(fit)
+    free_cap = int(0.6 * torch.cuda.mem_get_info(dev)[0]) if dev.type == "cuda" else max_arena_bytes
+    max_arena_bytes = min(max_arena_bytes, free_cap)        # never ask for more than 60 % of what is free now
+    fit = [e for e in spacings if n * (slab + e * two_mb) + two_mb <= max_arena_bytes]
+    if not fit:
+        raise RuntimeError(f"tune_placement: {n} fields of {slab} B do not fit 60 % of the free device memory")
+    spacings = tuple(fit)
     emax = max(spacings)
     span = n * (slab + emax * two_mb) + two_mb
-    # the same relative placement also differs by WHERE in the allocation it sits (profiles/r02/layout_scan.txt, "shifted"):
-    # a few whole-placement shifts are candidates too, as far as the arena may grow
     shifts = [int(sh) << 20 for sh in shifts_mb
-              if span + (int(sh) << 20) <= max_arena_bytes and (int(sh) << 20) <= 4 * span] or [0]
-    buf = torch.zeros((span + max(shifts)) // item, dtype=dt, device=dev)
+              if span + (int(sh) << 20) <= max_arena_bytes and (int(sh) << 20) <= max_shift_spans * span] or [0]
+    grid = [(e, st, sh) for sh in shifts for e in spacings for st in staggers]
+    grid += [(e, st, int(sh) << 20) for e in wide_spacings for sh in wide_shifts_mb for st in staggers
+             if n * (slab + e * two_mb) + two_mb + (int(sh) << 20) <= max_arena_bytes]
+    arena_need = max(n * (slab + e * two_mb) + two_mb + sh for e, _, sh in grid)
+    buf = torch.zeros(arena_need // item, dtype=dt, device=dev)
     base = (-buf.data_ptr()) % two_mb
     count = (nz + 1) * nx
 
@@ -191,8 +203,7 @@ def tune_placement(nx: int, nz: int, dtype: Any, device: Any, order, sources, la
     t_default = timed(warm)
     default = (default[0], default[1], 0)
     results = [(t_default,) + default]
-    cands = [(e, st, 0) for e in spacings for st in staggers if (e, st, 0) != default]
-    cands += [(e, st, sh) for sh in shifts[1:] for e in spacings for st in staggers]
+    cands = [c for c in grid if c != default]
     # as many candidates as fit `budget_s` of GPU time (big fields: fewer), spread evenly over the list
     per_cand = (2 + rounds * launches) * t_default * 1e-3 * 1.3
     keep = max(7, min(len(cands), int(budget_s / max(per_cand, 1e-6))))
@@ -219,6 +230,8 @@ def tune_placement(nx: int, nz: int, dtype: Any, device: Any, order, sources, la
               "slab_bytes": int(slab), "arena_bytes": int(buf.numel() * item),
               "first_pass_top": [(round(c[0], 4), c[1], c[2], c[3] >> 20) for c in sorted(results)[:8]],
               "second_pass": [(round(c[0], 4), c[1], c[2], c[3] >> 20) for c in finals]}
+    if keep_all:                 # every first-pass timing (profiles/placement_distribution.py)
+        report["first_pass_all"] = [(round(c[0], 4), c[1], c[2], c[3] >> 20) for c in results]
     return fields, report
 
 

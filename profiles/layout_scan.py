@@ -110,6 +110,31 @@ def main():
             cands[f"spacing +{e}x2MB stagger 2304"] = [i * (slab2m + e * two_mb) + (i * 2304) % 65536 for i in range(nfields)]
         for j in range(int(opts["random"])):
             cands[f"random #{j}"] = [i * (slab2m + 2 * two_mb) + int(rng.integers(0, 16384)) * 256 for i in range(nfields)]
+    if "split" in opts:          # --split=<GB> [--arena_gb=N]: is there a coarse ABSOLUTE-address structure?  For every multiple X of
+        # <GB> GiB (absolute virtual address) inside an N-GiB arena: inputs packed right below X and outputs right above it,
+        # against all 26 fields below X and all above X (dense 2-MB slabs, stagger 2304)
+        step_b = int(float(opts["split"]) * (1 << 30))
+        want = int(opts.get("arena_gb", 80)) << 30
+        if want > arena_bytes:
+            del arena
+            arena_bytes = want
+            arena = torch.zeros(arena_bytes // item, dtype=storage.torch_dtype(np_dtype), device=dev)
+            base0 = (-arena.data_ptr()) % (2 << 20)
+        start = arena.data_ptr() + base0
+        print(f"arena {arena_bytes >> 30} GiB at {arena.data_ptr():#x}; placements start at {start:#x}")
+        cands = {"slab2m stagger 0": cands["slab2m stagger 0"]}
+        nin = len(NL_IN)
+        x = (start // step_b + 1) * step_b
+        while x + (nfields + 1) * slab2m < arena.data_ptr() + arena_bytes:
+            rel = x - start
+            if rel >= nfields * slab2m:
+                tag = f"{x / (1 << 30):7.2f} GiB"
+                cands[f"in | out split at {tag}"] = ([rel - (nin - i) * slab2m + (i * 2304) % 65536 for i in range(nin)]
+                                                     + [rel + (i - nin) * slab2m + (i * 2304) % 65536 for i in range(nin, nfields)])
+                cands[f"all below        {tag}"] = [rel - (nfields - i) * slab2m + (i * 2304) % 65536 for i in range(nfields)]
+                cands[f"all above        {tag}"] = [rel + i * slab2m + (i * 2304) % 65536 for i in range(nfields)]
+                cands[f"half | half at   {tag}"] = [rel + (i - nfields // 2) * slab2m + (i * 2304) % 65536 for i in range(nfields)]
+            x += step_b
     arena_need = max(max(v) for v in cands.values()) + fbytes + base0 + (1 << 20)
     if arena_need > arena_bytes:
         del arena

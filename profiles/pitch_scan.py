@@ -42,7 +42,27 @@ def main():
     two_mb = 2 << 20
     maxf = (nz + 1) * (nx + max(pads)) * item
     arena_bytes = nfields * (maxf + (max(extras) + 2) * two_mb) + (4 << 20)
-    arena = torch.zeros(arena_bytes // item, dtype=storage.torch_dtype(np_dtype), device=dev)
+    spads = [int(x) for x in opts.get("spads", "0").split(",")]        # bytes added to the slab spacing (any multiple of 256)
+    arena_bytes += nfields * max(spads)
+    raw = None
+    if opts.get("contiguous"):   # --contiguous=1: a PHYSICALLY contiguous arena (hipExtMallocWithFlags, hipDeviceMallocContiguous):
+        import ctypes as C       # the same physical layout in every process, so what is measured is the layout's, not the lottery's
+
+        hip = C.CDLL([l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l][0])
+        hip.hipExtMallocWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_uint]
+        ptr = C.c_void_p()
+        rc = hip.hipExtMallocWithFlags(C.byref(ptr), arena_bytes, 0x4)
+        assert rc == 0 and ptr.value, f"contiguous allocation of {arena_bytes >> 20} MiB failed: {rc}"
+
+        class Raw:
+            __cuda_array_interface__ = {"shape": (arena_bytes,), "typestr": "|u1", "data": (ptr.value, False), "version": 2}
+
+        raw = Raw()
+        arena = torch.as_tensor(raw, device=dev).view(storage.torch_dtype(np_dtype))
+        arena.zero_()
+        print(f"contiguous arena {arena_bytes >> 20} MiB at {ptr.value:#x}")
+    else:
+        arena = torch.zeros(arena_bytes // item, dtype=storage.torch_dtype(np_dtype), device=dev)
     base0 = (-arena.data_ptr()) % two_mb
     stream = torch.cuda.current_stream().cuda_stream
     qsat_src = storage.zeros(nx, nz, np_dtype, dev)
@@ -51,10 +71,10 @@ def main():
     src = {n: (s["f_" + n] if n != "qsat" else storage.klayout(qsat_src)) for n in NL_IN}
     fn = getattr(lib, "cloudsc2_nl_" + sfx)
 
-    def run(pad, extra):
+    def run(pad, extra, spad=0):
         ls = nx + pad
         fbytes = (nz + 1) * ls * item
-        slab = (fbytes + 65536 + two_mb - 1) // two_mb * two_mb + extra * two_mb
+        slab = (fbytes + 65536 + two_mb - 1) // two_mb * two_mb + extra * two_mb + spad
         views = []
         for i in range(nfields):
             o = (base0 + i * slab + (i * 2304) % 65536) // item
@@ -84,12 +104,14 @@ def main():
         run(0, 0)
     ref = None
     for extra in extras:
-        for pad in pads + [pads[0]]:
-            t, kern, outs = run(pad, extra)
-            if ref is None:
-                ref = outs
-            same = all(bool(torch.equal(a, b)) for a, b in zip(ref, outs))
-            print(f"  extra {extra:2d}  pad {pad:6d} ({pad * item:7d} B)  {t:8.1f} us   {3567 * item * nx / t / 1e3:7.1f} GB/s   {kern}  results equal: {same}", flush=True)
+        for spad in spads:
+            for pad in pads + [pads[0]]:
+                t, kern, outs = run(pad, extra, spad)
+                if ref is None:
+                    ref = outs
+                same = all(bool(torch.equal(a, b)) for a, b in zip(ref, outs))
+                print(f"  extra {extra:2d}  spacing +{spad:8d} B  pitch pad {pad:6d} ({pad * item:7d} B)  {t:8.1f} us   "
+                      f"{3567 * item * nx / t / 1e3:7.1f} GB/s   {kern}  results equal: {same}", flush=True)
 
 
 if __name__ == "__main__":

@@ -52,8 +52,10 @@ def test_tuned_placement_is_bit_identical_and_reports_what_it_did(gpu):
     order = ["in_" + n for n in NL_IN] + ["out_" + n for n in NL_OUT]
     sources = {k: torch.as_tensor(v, device=gpu) for k, v in fields.items() if k != "in_qsat"}
     tuned, rep = storage.tune_placement(nx, nz, np.float64, gpu, order, sources, step, spacings=(0, 1, 2, 3),
-                                        staggers=(2304, 8448), budget_s=0.5)
-    assert rep["candidates"] >= 7 and rep["tuned_ms"] <= rep["default_ms"] and rep["stagger_bytes"] in (2304, 8448)
+                                        staggers=(2304, 8448), wide_spacings=(9,), wide_shifts_mb=(0, 64), budget_s=0.5)
+    assert rep["candidates"] >= 4 * 2 + 1 * 2 * 2           # the spacing x stagger x shift grid + the (optional) wide family
+    assert rep["tuned_ms"] <= rep["default_ms"] and rep["stagger_bytes"] in (2304, 8448)
+    assert rep["extra_spacing_x2MB"] in (0, 1, 2, 3, 9)
     assert set(tuned) == set(order)
     for k, src in sources.items():
         assert torch.equal(storage.klayout(tuned[k]), src), k                       # inputs copied in

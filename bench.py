@@ -75,6 +75,10 @@ def parse_args(argv=None):
                     help="where the step's 26 fields sit in HBM: 'tuned' (default) = storage.tune_placement calibrates the "
                          "spacing between field starts for this process with the step itself as the objective, before the "
                          "timed region; 'arena' = the default FieldArena layout; 'separate' = one torch allocation per field")
+    ap.add_argument("--collective", choices=["rccl", "gloo"], default="rccl",
+                    help="'gloo': REHEARSAL of the N-rank path on fewer GPUs than ranks - kernels run for real (rank r on "
+                         "cuda:(r mod device count), so ranks may share a GPU), the barrier and the reductions go through gloo "
+                         "on host tensors; the record says so and its value is not a scaling figure")
     ap.add_argument("--dry-run", action="store_true",
                     help="plumbing rehearsal without a GPU: gloo instead of RCCL, shard bookkeeping and the "
                          "reductions only, NO kernels (value is null) - used by the CPU tests of the launcher")
@@ -373,8 +377,12 @@ def main(argv=None):
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    rehearsal = args.collective == "gloo"
+    if rehearsal:
+        local_rank %= torch.cuda.device_count()          # ranks may share a GPU: every rank still runs its own shard's kernels
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    red_device = torch.device("cpu") if rehearsal else device      # where the (three, tiny) reductions' tensors live
     dist = None
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:
         # one process per GPU under torch.distributed.run; backend "nccl" is RCCL on ROCm.  (Also taken
@@ -382,7 +390,10 @@ def main(argv=None):
         import torch.distributed as dist
 
         with _StdoutToStderr():
-            dist.init_process_group("nccl", device_id=device)
+            if rehearsal:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=device)
             dist.barrier()          # creates the RCCL communicator (and prints its banner) now
             torch.cuda.synchronize()
 
@@ -611,7 +622,7 @@ def main(argv=None):
     barrier()                               # closing bracket; the job time is the MAX over ranks taken below
     gc.enable()
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -657,6 +668,7 @@ def main(argv=None):
     norm = torch.stack([storage.klayout(outs["out_" + n]).double().abs().sum() for n in NL_OUT])
     finite = all(bool(torch.isfinite(storage.klayout(v)[: nz]).all()) for v in outs.values())
     if dist is not None:
+        norm = norm.to(red_device)
         dist.all_reduce(norm, op=dist.ReduceOp.SUM)
     norm = [float(x) for x in norm.cpu()]
 
@@ -664,7 +676,10 @@ def main(argv=None):
         res = base_record(args, world, nx, nz, value=total * args.steps / elapsed,
                           ms_per_step=1e3 * elapsed / args.steps,
                           ranks=dist.get_world_size() if dist is not None else None,
-                          backend="nccl (RCCL)" if dist is not None else "none (single process)")
+                          backend=("gloo (rehearsal: kernels real, ranks may share a GPU - not a scaling figure)" if rehearsal
+                                   else "nccl (RCCL)") if dist is not None else "none (single process)")
+        if rehearsal and dist is not None:
+            res["rccl_ranks"], res["rehearsal_ranks"] = None, dist.get_world_size()
         res["prewarm_steps"] = prewarm
         res["placement"] = placement
         res["outputs_finite"] = finite

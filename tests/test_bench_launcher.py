@@ -101,3 +101,25 @@ def test_bench_line_carries_the_contract_on_the_gpu(gpu):
     assert pc["passed"] and pc["points_outside_tolerance"] == 0 and pc["columns"] == 256 and pc["fields"] == 11
     assert 0 <= pc["max_err_over_field_scale"] < 1e-10
     assert d["fused_step"]["results_equal_unfused"] is True
+
+
+@pytest.mark.gpu
+def test_two_ranks_with_real_kernels_reproduce_the_one_process_result(gpu):
+    """`--collective gloo`: the N-rank path with REAL kernels on fewer GPUs than ranks (both ranks on this box's one GPU; barrier
+    and reductions through gloo).  Two shards of 8 192 columns must give the validation norms of ONE process on the same
+    16 384 global columns - the shards are slices of one problem, eta comes from global column 0, the SUM all-reduce adds up."""
+    common = ("--steps", "3", "--warmup", "1", "--cpu-cols", "0", "--no-extra-rooflines", "--no-roofline-events",
+              "--placement", "separate")
+    one = _run("--cols", "16384", *common)
+    assert one.returncode == 0, one.stderr[-3000:]
+    two = _run("--gpus", "2", "--collective", "gloo", "--cols", "8192", *common)
+    assert two.returncode == 0, two.stderr[-3000:]
+    lines = [l for l in two.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, two.stdout[-2000:]
+    d1, d2 = json.loads(one.stdout.strip().splitlines()[-1]), json.loads(lines[0])
+    assert d2["n_gpus"] == 2 and d2["rehearsal_ranks"] == 2 and d2["rccl_ranks"] is None
+    assert d2["collective_backend"].startswith("gloo (rehearsal")
+    assert d2["config"]["columns_per_gpu"] == 8192 and d2["config"]["columns_total"] == 16384 == d1["config"]["columns_total"]
+    assert d2["outputs_finite"] is True and d2["value"] > 0
+    for name, v1 in d1["validation_norm"].items():
+        assert d2["validation_norm"][name] == pytest.approx(v1, rel=1e-12, abs=1e-300), name

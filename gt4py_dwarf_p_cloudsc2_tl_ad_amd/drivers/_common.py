@@ -207,3 +207,11 @@ def tune_field_placement(field_dicts, objective, **tuner_kw) -> Dict[str, Any]:
             da.data = fields[n].as_subclass(FieldTensor)
     report["fields"] = len(groups)
     return report
+
+
+def report_placement(rep: Dict[str, Any], unit: str = "run") -> None:
+    """the line the drivers print after `--tune-placement`"""
+    print(f"[cloudsc2-hip] field placement tuned over {rep.get('candidates')} candidates: "
+          f"{rep.get('default_ms', 0):.4f} -> {rep.get('tuned_ms', 0):.4f} ms per {unit} "
+          f"(+{rep.get('extra_spacing_x2MB')} x 2 MB slab spacing, stagger {rep.get('stagger_bytes')} B, "
+          f"shift {rep.get('shift_MB')} MB, {rep.get('fields')} fields)")

@@ -9,7 +9,8 @@ from ..framework.output import print_performance, write_performance_to_csv, writ
 from ..framework.timing import timing
 from ..framework.validation import validate
 from ..physics import Cloudsc2NL, Cloudsc2NLSaturation, Saturation
-from ._common import DATA_DIR, add_common_options, init_distributed_from_env, setup, tune_field_placement
+from ._common import (DATA_DIR, add_common_options, init_distributed_from_env, report_placement, setup,
+                      tune_field_placement)
 
 
 def core(args):
@@ -40,9 +41,7 @@ def core(args):
         rep = tune_field_placement([state, diags, tends], one_run)
         cfg.gt4py_config.exec_info = saved
         ctx["placement"] = rep
-        print(f"[cloudsc2-hip] field placement tuned over {rep.get('candidates')} candidates: "
-              f"{rep.get('default_ms', 0):.4f} -> {rep.get('tuned_ms', 0):.4f} ms per run "
-              f"(+{rep.get('extra_spacing_x2MB')} x 2 MB slab spacing, stagger {rep.get('stagger_bytes')} B, {rep.get('fields')} fields)")
+        report_placement(rep, "run")
     graph = None
     if args.graph:
         # --graph: the timed region is captured ONCE into a HIP graph (torch.cuda.CUDAGraph on a side stream; the

@@ -6,7 +6,7 @@ import statistics
 
 from ..framework.timing import timing
 from ..harness import SymmetryTest
-from ._common import add_common_options, init_distributed_from_env, setup
+from ._common import add_common_options, init_distributed_from_env, report_placement, setup, tune_field_placement
 
 
 def core(args):
@@ -17,6 +17,12 @@ def core(args):
                       yrncl_params=p["yrncl"], yrphnc_params=p["yrphnc"], enable_checks=cfg.sympl_enable_checks,
                       gt4py_config=cfg.gt4py_config, ad_traj_fix=args.ad_traj_fix)
     ok = st(ctx["state"], ctx["dt"], enable_validation=cfg.enable_validation)   # warm-up + the validated call
+    if args.tune_placement:
+        # build extension: the ~80 fields of the test are re-placed in HBM where a whole run is fastest
+        ctx["placement"] = tune_field_placement(
+            [ctx["state"], st.diags_sat, st.state_i, st.tends_tl, st.diags_tl, st.tends_ad, st.diags_ad],
+            lambda: st(ctx["state"], ctx["dt"], enable_validation=False), budget_s=8.0)
+        report_placement(ctx["placement"], "run")
     runtimes = []
     for i in range(cfg.num_runs):
         with timing(f"run_{i}") as timer:
@@ -34,6 +40,8 @@ def main(argv=None):
     add_common_options(ap)
     ap.add_argument("--ad-traj-fix", action="store_true",
                     help="use the AD kernel whose freezing tests match NL/TL (build extension, DESIGN.md 3.3)")
+    ap.add_argument("--tune-placement", action="store_true",
+                    help="measure and fix the HBM placement of the test's fields for this process (storage.tune_placement)")
     args = ap.parse_args(argv)
     init_distributed_from_env()
     return core(args)

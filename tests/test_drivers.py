@@ -332,3 +332,27 @@ def test_nonlinear_driver_with_tuned_field_placement(gpu, capsys):
     for d in ("tends", "diags"):
         for k, v in a[d].items():
             assert torch.equal(v.data, b[d][k].data), k
+
+
+@pytest.mark.gpu
+def test_taylor_and_symmetry_drivers_with_tuned_field_placement(gpu, capsys):
+    """`--tune-placement` on the two validation drivers: every field of the test (state, increments, perturbed state, NL / TL / AD
+    outputs) is re-placed with a whole run as the objective; norms, verdicts and adjoints are those of the plain run, bit for bit."""
+    import torch
+
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.drivers import run_symmetry_test, run_taylor_test
+
+    base = ["--backend", "hip", "--num-cols", "4096", "--num-runs", "2", "--input", "synthetic"]
+    a = run_taylor_test.main(base)
+    b = run_taylor_test.main(base + ["--tune-placement"])
+    out = capsys.readouterr().out
+    assert out.count("field placement tuned over") == 1 and b["placement"]["fields"] >= 80
+    assert np.array_equal(a["norms"], b["norms"]) and a["passed"] == b["passed"]
+    c = run_symmetry_test.main(base)
+    d = run_symmetry_test.main(base + ["--tune-placement"])
+    out = capsys.readouterr().out
+    assert out.count("field placement tuned over") == 1 and d["placement"]["fields"] >= 70
+    assert c["passed"] == d["passed"] and c["detail"] == d["detail"]
+    for k, v in c["state"].items():
+        if hasattr(v, "data") and isinstance(v.data, torch.Tensor):
+            assert torch.equal(v.data, d["state"][k].data), k

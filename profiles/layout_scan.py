@@ -41,7 +41,29 @@ def main():
     fbytes = (nz + 1) * nx * item
     nfields = len(NL_IN) + len(NL_OUT)
     arena_bytes = nfields * (fbytes + (8 << 20)) + (4 << 20)
-    arena = torch.zeros(arena_bytes // item, dtype=storage.torch_dtype(np_dtype), device=dev)
+    keep_raw = []
+
+    def alloc(nbytes):
+        """the arena: a torch allocation, or with --contiguous=1 PHYSICALLY contiguous memory (hipExtMallocWithFlags,
+        hipDeviceMallocContiguous) wrapped through __cuda_array_interface__"""
+        if not opts.get("contiguous"):
+            return torch.zeros(nbytes // item, dtype=storage.torch_dtype(np_dtype), device=dev)
+        hip = ctypes.CDLL([l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l][0])
+        hip.hipExtMallocWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t, ctypes.c_uint]
+        ptr = ctypes.c_void_p()
+        rc = hip.hipExtMallocWithFlags(ctypes.byref(ptr), nbytes, 0x4)
+        assert rc == 0 and ptr.value, f"contiguous allocation of {nbytes >> 20} MiB failed: {rc}"
+
+        class Raw:
+            __cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr.value, False), "version": 2}
+
+        keep_raw.append(Raw())
+        print(f"contiguous arena {nbytes >> 20} MiB at {ptr.value:#x}")
+        t = torch.as_tensor(keep_raw[-1], device=dev).view(storage.torch_dtype(np_dtype))
+        t.zero_()
+        return t
+
+    arena = alloc(arena_bytes)
     base0 = (-arena.data_ptr()) % (2 << 20)              # start the placements on a 2 MB boundary of the address space
     stream = torch.cuda.current_stream().cuda_stream
     qsat_src = storage.zeros(nx, nz, np_dtype, dev)
@@ -118,7 +140,7 @@ def main():
         if want > arena_bytes:
             del arena
             arena_bytes = want
-            arena = torch.zeros(arena_bytes // item, dtype=storage.torch_dtype(np_dtype), device=dev)
+            arena = alloc(arena_bytes)
             base0 = (-arena.data_ptr()) % (2 << 20)
         start = arena.data_ptr() + base0
         print(f"arena {arena_bytes >> 30} GiB at {arena.data_ptr():#x}; placements start at {start:#x}")
@@ -135,11 +157,21 @@ def main():
                 cands[f"all above        {tag}"] = [rel + i * slab2m + (i * 2304) % 65536 for i in range(nfields)]
                 cands[f"half | half at   {tag}"] = [rel + (i - nfields // 2) * slab2m + (i * 2304) % 65536 for i in range(nfields)]
             x += step_b
+    if "jump" in opts:           # --jump=<first field of the group> [--contiguous=1]: 192 MB spacing, the fields from that index on moved
+        # by an extra offset D - imitates the junction between two physical blocks that the fast shifts of a torch arena straddle
+        g0 = int(opts["jump"])
+        mb = 1 << 20
+        base_sp = 192 * mb
+        ds = [0] + [k * 256 * mb for k in range(1, 25)] + [2 * mb, 6 * mb, 10 * mb, 18 * mb, 34 * mb, 66 * mb, 130 * mb, 258 * mb, 514 * mb,
+                                                          1026 * mb, 2050 * mb, 4098 * mb, 98 * mb, 354 * mb, 866 * mb, 1890 * mb, 3426 * mb]
+        cands = {"slab2m stagger 0": cands["slab2m stagger 0"]}
+        for d in ds:
+            cands[f"fields {g0}.. moved by {d // mb:5d} MB"] = [i * base_sp + (i * 2304) % 65536 + (d if i >= g0 else 0) for i in range(nfields)]
     arena_need = max(max(v) for v in cands.values()) + fbytes + base0 + (1 << 20)
     if arena_need > arena_bytes:
         del arena
         arena_bytes = arena_need
-        arena = torch.zeros(arena_bytes // item, dtype=storage.torch_dtype(np_dtype), device=dev)
+        arena = alloc(arena_bytes)
         base0 = (-arena.data_ptr()) % (2 << 20)
     print(f"cloudsc2_nl {prec} {nx} columns, {torch.cuda.get_device_name(0)}; field {fbytes} B, 2-MB slab {slab2m} B; median of {rounds} x 5 launches")
     ref = "slab2m stagger 0"

@@ -140,6 +140,10 @@ def tune_placement(nx: int, nz: int, dtype: Any, device: Any, order, sources, la
     spacings = tuple(fit)
     emax = max(spacings)
     span = n * (slab + emax * two_mb) + two_mb
+    if os.environ.get("CLOUDSC2_TUNE_SHIFTS_MB"):      # dev switch for A/B runs of the grid (profiles/tuner_ab.sh)
+        shifts_mb = tuple(int(x) for x in os.environ["CLOUDSC2_TUNE_SHIFTS_MB"].split(","))
+        max_arena_bytes = max(max_arena_bytes, min(free_cap, 96 << 30))
+        max_shift_spans = 1e9
     shifts = [int(sh) << 20 for sh in shifts_mb
               if span + (int(sh) << 20) <= max_arena_bytes and (int(sh) << 20) <= max_shift_spans * span] or [0]
     grid = [(e, st, sh) for sh in shifts for e in spacings for st in staggers]

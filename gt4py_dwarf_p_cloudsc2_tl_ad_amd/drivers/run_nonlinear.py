@@ -122,7 +122,8 @@ def main(argv=None):
     ap.add_argument("--graph", action="store_true",
                     help="capture the timed region in a HIP graph and replay it (launch-bound loop -> one host call)")
     ap.add_argument("--tune-placement", action="store_true",
-                    help="measure and fix the HBM placement of the timed region's fields for this process (storage.tune_placement)")
+                    help="measure and fix the HBM placement of the timed region's fields for this process "
+                         "(storage.tune_placement)")
     ap.add_argument("--atol", type=float, default=None)
     ap.add_argument("--rtol", type=float, default=None)
     args = ap.parse_args(argv)

@@ -51,6 +51,14 @@ constexpr bool kADPark = ((CS2_AD_PARK) & (sizeof(T) == 8 ? 1 : 2)) != 0;
     X(lude) X(qt) X(qcrit) X(qsat) X(qpd) X(qcd) X(tmp3) X(rden) X(crh2) X(supsat) X(fac) X(cor) X(facw) X(faci) X(ri)  \
     X(rl) X(esdp1) X(foeew) X(sech2) X(qc3)
 #define CS2_AD_PARK_COUNT 34
+// CS2_AD_KEEP_MB: cache-resident turnaround.  Sweep 1 ends at level nz-1 and sweep 2 starts there, re-reading the 16
+// inputs + 2 fluxes of every level; the last levels sweep 1 touched can still be in the 256 MB memory-side cache when
+// sweep 2 asks for them - if neither side marked them non-temporal.  The launcher turns this budget into a number of
+// bottom levels (18 words x level stride each) whose sweep-1 loads, flux stores and sweep-2 loads use the default
+// policy; every other access of the kernel stays non-temporal.  0 = off.
+#ifndef CS2_AD_KEEP_MB
+#define CS2_AD_KEEP_MB 0
+#endif
 #ifndef CS2_AD_PIN
 #define CS2_AD_PIN 3    // fp64 constants pinned in VGPRs: bit 0 = the physical constants, bit 1 = the exp coefficients
 #endif
@@ -62,9 +70,30 @@ struct ADIn {
     T ap, aph1, lu1, lude, mfd, mfu, q, qi, ql, qsat, supsat, t, tq, tqi, tql, tt;
 };
 
+// `keep`: wave-uniform; the level's 16 words are loaded with the default cache policy instead of non-temporally
+// (CS2_AD_KEEP_MB below: the levels where sweep 1 ends are the levels where sweep 2 starts).
 template <typename T>
-__device__ __forceinline__ ADIn<T> ad_load(const CPtrs<T, NL_NUM_IN>& in, uint32_t lsb, uint32_t o) {
+__device__ __forceinline__ ADIn<T> ad_load(const CPtrs<T, NL_NUM_IN>& in, uint32_t lsb, uint32_t o, bool keep = false) {
     ADIn<T> x;
+    if (keep) {
+        x.ap = ldg_keep(in.p[NL_IN_AP], o);
+        x.aph1 = ldg_keep(in.p[NL_IN_APH], o + lsb);
+        x.lu1 = ldg_keep(in.p[NL_IN_LU], o + lsb);
+        x.lude = ldg_keep(in.p[NL_IN_LUDE], o);
+        x.mfd = ldg_keep(in.p[NL_IN_MFD], o);
+        x.mfu = ldg_keep(in.p[NL_IN_MFU], o);
+        x.q = ldg_keep(in.p[NL_IN_Q], o);
+        x.qi = ldg_keep(in.p[NL_IN_QI], o);
+        x.ql = ldg_keep(in.p[NL_IN_QL], o);
+        x.qsat = ldg_keep(in.p[NL_IN_QSAT], o);
+        x.supsat = ldg_keep(in.p[NL_IN_SUPSAT], o);
+        x.t = ldg_keep(in.p[NL_IN_T], o);
+        x.tq = ldg_keep(in.p[NL_IN_TND_CML_Q], o);
+        x.tqi = ldg_keep(in.p[NL_IN_TND_CML_QI], o);
+        x.tql = ldg_keep(in.p[NL_IN_TND_CML_QL], o);
+        x.tt = ldg_keep(in.p[NL_IN_TND_CML_T], o);
+        return x;
+    }
     x.ap = ldg(in.p[NL_IN_AP], o);
     x.aph1 = ldg(in.p[NL_IN_APH], o + lsb);
     x.lu1 = ldg(in.p[NL_IN_LU], o + lsb);
@@ -82,6 +111,16 @@ __device__ __forceinline__ ADIn<T> ad_load(const CPtrs<T, NL_NUM_IN>& in, uint32
     x.tql = ldg(in.p[NL_IN_TND_CML_QL], o);
     x.tt = ldg(in.p[NL_IN_TND_CML_T], o);
     return x;
+}
+// store / load with the cache policy chosen by a wave-uniform flag (sweep 1's fluxes that sweep 2 reads back)
+template <typename T>
+__device__ __forceinline__ void stg_sel(T* base, uint32_t boff, T v, bool keep) {
+    if (keep) *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + boff) = v;
+    else stg(base, boff, v);
+}
+template <typename T>
+__device__ __forceinline__ T ldg_sel(const T* base, uint32_t boff, bool keep) {
+    return keep ? ldg_keep(base, boff) : ldg(base, boff);
 }
 
 // Saved state of the two saturation-adjustment iterations (cuadjtqs:53-91), including the
@@ -876,7 +915,7 @@ template <typename T, bool REG, bool FIX, bool EVAP>
 __global__ void __launch_bounds__(kColBlock)
 ad_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, NL_NUM_IN> in,
           CPtrs<T, NL_NUM_OUT> adj, const T* __restrict__ eta, MPtrs<T, NL_NUM_OUT> out, MPtrs<T, NL_NUM_IN> oadj,
-          T dt) {
+          T dt, int keep_from) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     T* s_eta = reinterpret_cast<T*>(smem_raw);
     T* s_scalm = s_eta + (nz + 1);
@@ -917,10 +956,11 @@ ad_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
         T rfl = T(0.0), sfl = T(0.0), covptot = T(0.0);
         T aph_k = ldg(in.p[NL_IN_APH], colb);
         uint32_t o = colb;
-        ADIn<T> xa = ad_load<T>(in, lsb, o);
+        ADIn<T> xa = ad_load<T>(in, lsb, o, 0 >= keep_from);
         for (int k = 0; k < nz; ++k) {
             ADIn<T> xn = xa;
-            if (k + 1 < nz) xn = ad_load<T>(in, lsb, o + lsb);
+            const bool keep_n = k + 1 >= keep_from;   // level k+1 (and the fluxes entering it) stay cacheable
+            if (k + 1 < nz) xn = ad_load<T>(in, lsb, o + lsb, keep_n);
             ADTraj<T> r;
             ad_forward<T, FIX, EVAP>(e, kc, xk, xa, aph_k, k, s_eta[k], s_scalm[k], crh, dt, rfl, sfl, covptot, aph_s,
                                      r);
@@ -932,8 +972,8 @@ ad_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
             stg(out.p[NL_OUT_TND_T], o, r.tnd_t);
             stg(out.p[NL_OUT_TND_QL], o, r.tnd_ql);
             stg(out.p[NL_OUT_TND_QI], o, r.tnd_qi);
-            stg(out.p[NL_OUT_FPLSL], o + lsb, r.rfln);
-            stg(out.p[NL_OUT_FPLSN], o + lsb, r.sfln);
+            stg_sel(out.p[NL_OUT_FPLSL], o + lsb, r.rfln, keep_n);
+            stg_sel(out.p[NL_OUT_FPLSN], o + lsb, r.sfln, keep_n);
             stg(out.p[NL_OUT_FHPSL], o + lsb, -r.rfln * e.RLVTT);
             stg(out.p[NL_OUT_FHPSN], o + lsb, -r.sfln * e.RLSTT);
             rfl = r.rfln;
@@ -952,11 +992,11 @@ ad_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
     {
         int k = nz - 1;
         uint32_t o = uint32_t(k) * lsb + colb;
-        ADIn<T> xa = ad_load<T>(in, lsb, o);
+        ADIn<T> xa = ad_load<T>(in, lsb, o, k >= keep_from);
         ADForce<T> fa = ad_load_force<T, EVAP>(adj, e, lsb, o);
-        T aph_k = ldg(in.p[NL_IN_APH], o);
-        T sfl = ldg(const_cast<const T*>(out.p[NL_OUT_FPLSN]), o);
-        T rfl = ldg(const_cast<const T*>(out.p[NL_OUT_FPLSL]), o);
+        T aph_k = ldg_sel(in.p[NL_IN_APH], o, k >= keep_from);
+        T sfl = ldg_sel(const_cast<const T*>(out.p[NL_OUT_FPLSN]), o, k >= keep_from);
+        T rfl = ldg_sel(const_cast<const T*>(out.p[NL_OUT_FPLSL]), o, k >= keep_from);
         T cov = EVAP ? ldg(const_cast<const T*>(park), o) : T(0.0);
         for (; k >= 0; --k) {
             ADIn<T> xn = xa;
@@ -964,12 +1004,13 @@ ad_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
             T aph_n = aph_k, sfl_n = sfl, rfl_n = rfl, cov_n = cov;
             if (k > 0) {
                 const uint32_t om = o - lsb;
-                xn = ad_load<T>(in, lsb, om);
+                const bool keep_m = k - 1 >= keep_from;
+                xn = ad_load<T>(in, lsb, om, keep_m);
                 xn.aph1 = aph_k;   // aph[k]: already here as this level's upper half level (the load above is dropped)
                 fn = ad_load_force<T, EVAP>(adj, e, lsb, om);
-                aph_n = ldg(in.p[NL_IN_APH], om);
-                sfl_n = ldg(const_cast<const T*>(out.p[NL_OUT_FPLSN]), om);
-                rfl_n = ldg(const_cast<const T*>(out.p[NL_OUT_FPLSL]), om);
+                aph_n = ldg_sel(in.p[NL_IN_APH], om, keep_m);
+                sfl_n = ldg_sel(const_cast<const T*>(out.p[NL_OUT_FPLSN]), om, keep_m);
+                rfl_n = ldg_sel(const_cast<const T*>(out.p[NL_OUT_FPLSL]), om, keep_m);
                 if constexpr (EVAP) cov_n = ldg(const_cast<const T*>(park), om);
             }
             ADTraj<T> r;
@@ -1032,6 +1073,13 @@ int launch_ad(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
     if (smem > size_t(64) * 1024 && hipGetDevice(&dev) != hipSuccess) return -1;
     const bool reg = p.LREGCL != 0;
     const bool fix = p.AD_TRAJ_FIX != 0;
+    // cache-resident turnaround (CS2_AD_KEEP_MB): bottom levels whose 18 re-read words per column fit the budget
+    int keep_from = nz;
+    if (CS2_AD_KEEP_MB > 0) {
+        const uint64_t per_level = uint64_t(18) * uint64_t(ls) * sizeof(T);
+        const int levels = int((uint64_t(CS2_AD_KEEP_MB) << 20) / (per_level ? per_level : 1));
+        keep_from = levels >= nz ? 0 : nz - levels;
+    }
 #define CS2_AD_LAUNCH(R, F, E)                                                                                         \
     do {                                                                                                               \
         auto kern = ad_kernel<T, R, F, E>;                                                                             \
@@ -1044,7 +1092,7 @@ int launch_ad(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
                 attr_set[dev & 63] = smem;                                                                             \
             }                                                                                                          \
         }                                                                                                              \
-        hipLaunchKernelGGL(kern, grid, block, smem, stream, e, kc, xk, nx, nz, ls, ci, ca, eta, co, coa, tdt);         \
+        hipLaunchKernelGGL(kern, grid, block, smem, stream, e, kc, xk, nx, nz, ls, ci, ca, eta, co, coa, tdt, keep_from);         \
     } while (0)
 #define CS2_AD_LAUNCH_E(R, F) \
     do {                      \

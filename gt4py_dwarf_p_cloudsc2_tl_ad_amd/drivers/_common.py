@@ -57,7 +57,8 @@ def add_common_options(ap: argparse.ArgumentParser) -> None:
     ap.add_argument("--input", default="auto",
                     help="'auto': <data dir>/input.h5 if readable, else its 100-column synthetic stand-in, tiled "
                          "to --num-cols like the real file; 'synthetic': --num-cols DISTINCT seeded columns "
-                         "(mixed regimes) generated on the device")
+                         "(mixed regimes) generated on the device; anything else: the path of an HDF5 file with the "
+                         "datasets of the reference's data/input.h5 (it must exist), tiled to --num-cols")
 
 
 def make_config(args) -> Tuple[PythonConfig, IOConfig]:
@@ -86,7 +87,12 @@ def setup(args) -> Dict[str, Any]:
     device = backend_device(gcfg)
     # "auto": the reader path (real input.h5 if readable, otherwise the 100-column synthetic stand-in
     # dataset of framework.iox, tiled to --num-cols exactly as the real file would be)
-    use_file = args.input == "auto"
+    use_file = args.input != "synthetic"
+    if use_file and args.input != "auto":
+        if not os.path.isfile(args.input):
+            raise FileNotFoundError(f"--input {args.input}: no such file ('auto' falls back to the synthetic stand-in, "
+                                    "an explicit path does not)")
+        cfg = cfg._with(input_file=os.path.abspath(args.input))
     if use_file:
         op = HDF5Operator(cfg.input_file, gt4py_config=gcfg)
         nz = int(np.asarray(op.f["KLEV"]).reshape(-1)[0])

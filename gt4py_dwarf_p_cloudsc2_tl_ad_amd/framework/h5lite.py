@@ -10,10 +10,13 @@ library with its default ("earliest") format settings:
   * version-1 object headers with continuation blocks;
   * dataspace versions 1 / 2 (simple, scalar); fixed-point and IEEE floating-point datatypes (little or big endian),
     enumerations (returned in their base integer type - h5py writes booleans so) and fixed-length strings (raw bytes);
-  * data layout version 3 (and 1 / 2), classes COMPACT and CONTIGUOUS.
+  * data layout version 3 (and 1 / 2), classes COMPACT and CONTIGUOUS, and - should the real `input.h5` turn out to be
+    written that way - CHUNKED with the version-1 chunk B-tree and the deflate / shuffle / fletcher32 filters.
 
-Anything else (chunked or compressed datasets, new-style groups with link messages / fractal heaps, compound or
-variable-length types) raises `NotImplementedError` naming the feature - read such a file with h5py.  The interface is the
+Anything else (new-style groups with link messages / fractal heaps, superblock 2 / 3 and version-2 object headers of
+`libver="latest"` files, compound or variable-length types, other filters, version-4 chunk indices) raises
+`H5UnsupportedError` (a `NotImplementedError`) whose `.feature` names what was met - such a file is never misread; read it
+with h5py.  The interface is the
 part of h5py's the reader path uses: `File(path)` is a read-only mapping name -> NumPy array (`f["PT"]`, `f.keys()`,
 `name in f`), nested groups by "/"-separated names.  Format reference: "HDF5 File Format Specification Version 2.0".
 """
@@ -32,6 +35,15 @@ _UNDEF = {4: 0xFFFFFFFF, 8: 0xFFFFFFFFFFFFFFFF}
 
 class H5FormatError(ValueError):
     pass
+
+
+class H5UnsupportedError(NotImplementedError):
+    """A valid HDF5 construct outside the subset this reader implements; `.feature` is a short stable name for it
+    ("superblock-v2", "object-header-v2", "new-style-group", "filter", "chunk-index", "datatype", "layout", ...)."""
+
+    def __init__(self, feature: str, message: str) -> None:
+        super().__init__(message + " - use h5py")
+        self.feature = feature
 
 
 class File(Mapping):
@@ -88,8 +100,8 @@ class File(Mapping):
                 raise H5FormatError(f"{self.filename}: not an HDF5 file (signature not found)")
         version = b[base + 8]
         if version not in (0, 1):
-            raise NotImplementedError(f"{self.filename}: HDF5 superblock version {version} (written with libver='latest'?) "
-                                      "is outside the subset h5lite reads - use h5py")
+            raise H5UnsupportedError(f"superblock-v{version}", f"{self.filename}: HDF5 superblock version {version} (written "
+                                     "with libver='latest'?) is outside the subset h5lite reads")
         self._so, self._sl = b[base + 13], b[base + 14]
         if self._so not in (4, 8) or self._sl not in (4, 8):
             raise H5FormatError(f"{self.filename}: offset / length sizes {self._so} / {self._sl}")
@@ -111,7 +123,8 @@ class File(Mapping):
         a = self._base + addr
         if self._buf[a] != 1:
             if self._buf[a:a + 4] == b"OHDR":
-                raise NotImplementedError(f"{self.filename}: version-2 object headers are outside the subset h5lite reads")
+                raise H5UnsupportedError("object-header-v2", f"{self.filename}: version-2 object headers are outside the "
+                                         "subset h5lite reads")
             raise H5FormatError(f"{self.filename}: object header version {self._buf[a]} at {addr}")
         nmsg = self._u(a + 2, 2)
         size = self._u(a + 8, 4)
@@ -134,8 +147,8 @@ class File(Mapping):
             if mtype == 0x0011:                      # symbol table message: B-tree + local heap
                 return self._offset(body), self._offset(body + self._so)
             if mtype in (0x0002, 0x0006):            # link info / link message: new-style group
-                raise NotImplementedError(f"{self.filename}: new-style groups (link messages) are outside the subset "
-                                          "h5lite reads - use h5py")
+                raise H5UnsupportedError("new-style-group", f"{self.filename}: new-style groups (link messages) are outside "
+                                         "the subset h5lite reads")
         raise H5FormatError(f"{self.filename}: object at {header} is not a group")
 
     # ------------------------------------------------------------------ groups
@@ -186,6 +199,7 @@ class File(Mapping):
     def _read_dataset(self, header: int, name: str) -> np.ndarray:
         shape = dtype = None
         layout = None
+        filters = []
         for mtype, body, msize in self._messages(header):
             if mtype == 0x0001:
                 shape = self._dataspace(body)
@@ -194,11 +208,11 @@ class File(Mapping):
             elif mtype == 0x0008:
                 layout = (body, msize)
             elif mtype == 0x000B:
-                raise NotImplementedError(f"{self.filename}:{name}: filtered (compressed) datasets are outside the subset "
-                                          "h5lite reads - use h5py")
+                filters = self._filters(body, name)
         if shape is None or dtype is None or layout is None:
             raise H5FormatError(f"{self.filename}:{name}: dataspace / datatype / layout message missing")
         count = int(np.prod(shape, dtype=np.int64)) if shape else 1
+        native = dtype if dtype.kind == "S" else dtype.newbyteorder("=")
         body = layout[0]
         version = self._buf[body]
         if version == 3:
@@ -206,13 +220,20 @@ class File(Mapping):
             if cls == 1:                             # contiguous: address, size
                 addr, size = self._offset(body + 2), self._length(body + 2 + self._so)
                 if addr == _UNDEF[self._so]:         # never written: fill value (0)
-                    return np.zeros(shape, dtype if dtype.kind == "S" else dtype.newbyteorder("="))
+                    return np.zeros(shape, native)
                 start = self._base + addr
             elif cls == 0:                           # compact: size (2 bytes), data
                 size, start = self._u(body + 2, 2), body + 4
+            elif cls == 2:                           # chunked: rank + 1, B-tree address, chunk dims (the last = element size)
+                rank1 = self._buf[body + 2]
+                btree = self._offset(body + 3)
+                cdims = tuple(self._u(body + 3 + self._so + 4 * i, 4) for i in range(rank1))
+                if rank1 != len(shape) + 1 or cdims[-1] != dtype.itemsize:
+                    raise H5FormatError(f"{self.filename}:{name}: chunk dimensions {cdims} for shape {shape}")
+                return self._read_chunked(name, btree, shape, cdims[:-1], dtype, filters).astype(native, copy=False)
             else:
-                raise NotImplementedError(f"{self.filename}:{name}: chunked datasets are outside the subset h5lite reads "
-                                          "- use h5py")
+                raise H5UnsupportedError("layout", f"{self.filename}:{name}: data layout class {cls} (virtual dataset?) is "
+                                         "outside the subset h5lite reads")
         elif version in (1, 2):
             rank, cls = self._buf[body + 1], self._buf[body + 2]
             if cls == 1:
@@ -221,14 +242,89 @@ class File(Mapping):
                 p = body + 8 + 4 * rank
                 size, start = self._u(p, 4), p + 4
             else:
-                raise NotImplementedError(f"{self.filename}:{name}: chunked datasets are outside the subset h5lite reads")
+                raise H5UnsupportedError("layout", f"{self.filename}:{name}: chunked datasets with a version-{version} "
+                                         "layout message are outside the subset h5lite reads")
         else:
-            raise NotImplementedError(f"{self.filename}:{name}: data layout message version {version}")
+            raise H5UnsupportedError("chunk-index" if version == 4 else "layout",
+                                     f"{self.filename}:{name}: data layout message version {version} (libver='latest' chunk "
+                                     "indices) is outside the subset h5lite reads")
+        if filters:
+            raise H5FormatError(f"{self.filename}:{name}: a filter pipeline on a dataset that is not chunked")
         if size < count * dtype.itemsize:
             raise H5FormatError(f"{self.filename}:{name}: {size} bytes stored, {count * dtype.itemsize} needed")
         arr = np.frombuffer(self._buf, dtype=dtype, count=count, offset=start).reshape(shape)
-        native = dtype if dtype.kind == "S" else dtype.newbyteorder("=")
         return arr.astype(native, copy=True)         # detached from the mapping, native byte order
+
+    def _filters(self, body: int, name: str):
+        """Filter pipeline message (versions 1 / 2) -> [filter id, ...] in application order; only deflate (1), shuffle (2)
+        and fletcher32 (3) are implemented, anything else is refused by name."""
+        version, nfilt = self._buf[body], self._buf[body + 1]
+        if version not in (1, 2):
+            raise H5UnsupportedError("filter", f"{self.filename}:{name}: filter pipeline message version {version}")
+        p = body + (8 if version == 1 else 2)
+        out = []
+        for _ in range(nfilt):
+            fid = self._u(p, 2)
+            if version == 1 or fid >= 256:
+                namelen = self._u(p + 2, 2)
+                nvals = self._u(p + 6, 2)
+                p += 8 + (namelen + 7) // 8 * 8 if version == 1 else 8 + namelen
+            else:
+                nvals = self._u(p + 4, 2)
+                p += 6
+            p += 4 * nvals
+            if version == 1 and nvals % 2:
+                p += 4
+            if fid not in (1, 2, 3):
+                raise H5UnsupportedError("filter", f"{self.filename}:{name}: filter {fid} (only deflate, shuffle and "
+                                         "fletcher32 are implemented)")
+            out.append(fid)
+        return out
+
+    def _read_chunked(self, name, btree, shape, cshape, dtype, filters) -> np.ndarray:
+        import zlib
+
+        out = np.zeros(shape, dtype)                 # chunks that were never written keep the fill value (0)
+        if btree == _UNDEF[self._so]:
+            return out
+        rank = len(shape)
+        csize = int(np.prod(cshape, dtype=np.int64)) * dtype.itemsize
+
+        def node(addr):
+            n = self._base + addr
+            if self._buf[n:n + 4] != b"TREE" or self._buf[n + 4] != 1:
+                raise H5FormatError(f"{self.filename}:{name}: chunk B-tree node missing at {addr}")
+            level, used = self._buf[n + 5], self._u(n + 6, 2)
+            key = 8 + 8 * (rank + 1)                 # chunk size, filter mask, rank + 1 offsets
+            p = n + 8 + 2 * self._so
+            for i in range(used):
+                k = p + i * (key + self._so)
+                nbytes, mask = self._u(k, 4), self._u(k + 4, 4)
+                offs = tuple(self._u(k + 8 + 8 * j, 8) for j in range(rank))
+                child = self._offset(k + key)
+                if level > 0:
+                    node(child)
+                    continue
+                raw = bytes(self._buf[self._base + child:self._base + child + nbytes])
+                for j, fid in reversed(list(enumerate(filters))):
+                    if mask >> j & 1:                # this filter was skipped for this chunk
+                        continue
+                    if fid == 3:
+                        raw = raw[:-4]               # fletcher32: checksum appended, not verified
+                    elif fid == 1:
+                        raw = zlib.decompress(raw)
+                    else:                            # shuffle: byte i of every element stored together
+                        a = np.frombuffer(raw, np.uint8)
+                        nel = len(raw) // dtype.itemsize
+                        raw = a[:nel * dtype.itemsize].reshape(dtype.itemsize, nel).T.tobytes() + raw[nel * dtype.itemsize:]
+                if len(raw) < csize:
+                    raise H5FormatError(f"{self.filename}:{name}: chunk at {offs} holds {len(raw)} bytes, {csize} needed")
+                chunk = np.frombuffer(raw, dtype, count=csize // dtype.itemsize).reshape(cshape)
+                sl = tuple(slice(o, min(o + c, s)) for o, c, s in zip(offs, cshape, shape))
+                out[sl] = chunk[tuple(slice(0, x.stop - x.start) for x in sl)]
+
+        node(btree)
+        return out
 
     def _dataspace(self, body: int) -> Tuple[int, ...]:
         version, rank, flags = self._buf[body], self._buf[body + 1], self._buf[body + 2]
@@ -239,7 +335,7 @@ class File(Mapping):
                 raise H5FormatError(f"{self.filename}: null dataspace")
             p = body + 4
         else:
-            raise NotImplementedError(f"{self.filename}: dataspace message version {version}")
+            raise H5UnsupportedError("dataspace", f"{self.filename}: dataspace message version {version}")
         del flags                                    # maximum dimensions, if present, follow the current ones: not needed
         return tuple(self._length(p + i * self._sl) for i in range(rank))
 
@@ -257,10 +353,10 @@ class File(Mapping):
         elif cls == 8:                               # enumeration (h5py stores booleans so): values in the base integer type,
             return self._datatype(body + 8, name)    # whose own datatype message opens the properties
         else:
-            raise NotImplementedError(f"{self.filename}:{name}: datatype class {cls} is outside the subset h5lite reads "
-                                      "- use h5py")
+            raise H5UnsupportedError("datatype", f"{self.filename}:{name}: datatype class {cls} (compound / variable-length "
+                                     "/ ...) is outside the subset h5lite reads")
         if size not in (1, 2, 4, 8) or (kind == "f" and size == 1):
-            raise NotImplementedError(f"{self.filename}:{name}: {size}-byte {'float' if kind == 'f' else 'integer'}")
+            raise H5UnsupportedError("datatype", f"{self.filename}:{name}: {size}-byte {'float' if kind == 'f' else 'integer'}")
         return np.dtype(f"{order}{kind}{size}")
 
 

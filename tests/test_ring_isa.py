@@ -1,9 +1,17 @@
 """The hand-counted `s_waitcnt vmcnt(N)` of the cloudsc2_tl LDS-ring kernel is only right if the compiled level loop
 issues exactly the operations the count assumes: NI LDS-DMAs and 20 stores per level, and no wait hipcc added on its own.
 This test compiles csrc/cloudsc2_tl.hip to gfx950 assembly (no GPU needed) and checks exactly that, so a compiler or source
-change that breaks the count fails here and not as silent data corruption on the GPU.  (nl_ring_kernel's wait is one level of
-stores short of exact by design and hipcc multiplies its loop body per load-policy path, so a static count says nothing
-there; its guard is the determinism soak and the ring-vs-register tests on the GPU.)"""
+change that breaks the count fails here and not as silent data corruption on the GPU.
+
+nl_ring_kernel (the headline kernel) is guarded too.  hipcc multiplies its level body per cache-policy
+path (the in_qsat DMA, the optional pre-scan DMA), so lines cannot simply be counted; instead the kernel's control-flow
+graph is walked: on EVERY path from one steady-state wait `s_waitcnt vmcnt(NFULL)` to the next one there must be at
+least NI LDS-DMAs (NI + 1 with the pre-scan pair) and at least NSTORE stores, no ordinary load, and no vector-memory wait
+other than the three hand-written ones (NFULL, NHEAD, 0) - a wait that ALLOWS more outstanding operations than were issued
+after level k's DMAs would let the lane read a slot before its data arrived.
+
+`__graft_entry__.build()` runs these checks whenever it really recompiles the library, so a library built by a
+different hipcc cannot ship with a wrong count even where pytest never runs."""
 import os
 import re
 import subprocess
@@ -69,3 +77,124 @@ def test_tl_ring_loop_matches_the_hand_counted_wait(tl_asm, tname, ni):
         seen += 1
     assert seen == 4              # REG x EVAP instantiations
 
+
+
+# ------------------------------------------------------------------------------------------------ cloudsc2_nl ring
+@pytest.fixture(scope="module")
+def nl_asm(tmp_path_factory):
+    return _compile(tmp_path_factory, "cloudsc2_nl.hip")
+
+
+def _cfg(lines):
+    """Nodes of a kernel's control-flow graph, split at labels, branches and vector-memory waits.  Every node is
+    (kind counts, wait value or None, successors)."""
+    starts = {0}
+    label_at = {}
+    for i, l in enumerate(lines):
+        t = l.strip()
+        if (m := re.match(r"(\.LBB\d+_\d+):", t)):
+            starts.add(i)
+            label_at[m.group(1)] = i
+        if re.match(r"s_c?branch|s_endpgm", t):
+            starts.add(i + 1)
+        if t.startswith("s_waitcnt") and "vmcnt" in t:
+            starts.add(i)
+            starts.add(i + 1)
+    order = sorted(x for x in starts if x < len(lines))
+    nodes = {}
+    for a, b in zip(order, order[1:] + [len(lines)]):
+        body = [l.strip() for l in lines[a:b]]
+        wait = None
+        if body and body[0].startswith("s_waitcnt") and "vmcnt" in body[0]:
+            wait = int(re.search(r"vmcnt\((\d+)\)", body[0]).group(1))
+        succ = []
+        last = next((t for t in reversed(body) if t and not t.startswith(";")), "")
+        m = re.match(r"s_(c?)branch\w* (\.LBB\d+_\d+)", last)
+        if m:
+            succ.append(label_at[m.group(2)])
+            if m.group(1):
+                succ.append(b)
+        elif not last.startswith("s_endpgm"):
+            succ.append(b)
+        # the hand-written ring waits are the ones fused with the slot's LDS reads in one asm statement
+        ring_wait = wait is not None and b < len(lines) and lines[b].strip().startswith("ds_read_b")
+        nodes[a] = dict(ring_wait=ring_wait, dma=sum("global_load_lds" in t for t in body), st=sum(t.startswith("global_store") for t in body),
+                        ld=sum(bool(re.match(r"global_load_dword", t)) for t in body), wait=wait,
+                        succ=[x for x in succ if x < len(lines)])
+    return nodes
+
+
+def _between_waits(nodes, start, nfull):
+    """Over all static paths from the ring wait `start` to the next steady-state ring wait (paths end at ANY vector-memory
+    wait; only those ending at a vmcnt(NFULL) ring wait count): min / max stores, max ordinary loads, max LDS-DMAs, the min
+    of LDS-DMAs over the paths that issue at least one (the static graph also contains the infeasible combination
+    "`more` false at the issue, true at the wait" - the two tests are the same uniform condition - which issues none), and
+    the set of wait values met."""
+    import sys
+
+    sys.setrecursionlimit(20000)
+    INF = 10 ** 9
+    seen_waits = set()
+    memo = {}
+    BUSY = object()
+
+    def walk(n):
+        if n in memo:
+            # a node still being expanded = a static cycle through the level loop that bypasses all three waits (the same
+            # infeasible combination of the uniform `more` tests): ignored
+            return None if memo[n] is BUSY else memo[n]
+        nd = nodes[n]
+        if nd["wait"] is not None:
+            seen_waits.add(nd["wait"])
+            memo[n] = dict(st=(0, 0), ld=0, dma_max=0, dma_min_any=0, dma_min_some=INF) \
+                if (nd["wait"] == nfull and nd["ring_wait"]) else None
+            return memo[n]
+        memo[n] = BUSY
+        res = [r for r in (walk(s) for s in nd["succ"]) if r is not None]
+        if not res:
+            memo[n] = None
+            return None
+        d = nd["dma"]
+        any_min = min(r["dma_min_any"] for r in res)
+        memo[n] = dict(st=(nd["st"] + min(r["st"][0] for r in res), nd["st"] + max(r["st"][1] for r in res)),
+                       ld=nd["ld"] + max(r["ld"] for r in res), dma_max=d + max(r["dma_max"] for r in res),
+                       dma_min_any=d + any_min,
+                       dma_min_some=(d + any_min) if d > 0 else min(r["dma_min_some"] for r in res))
+        return memo[n]
+
+    res = [r for r in (walk(s) for s in nodes[start]["succ"]) if r is not None]
+    assert res, "the steady-state wait is not inside a loop"
+    return dict(st=(min(r["st"][0] for r in res), max(r["st"][1] for r in res)), ld=max(r["ld"] for r in res),
+                dma_max=max(r["dma_max"] for r in res), dma_min_some=min(r["dma_min_some"] for r in res),
+                waits=seen_waits)
+
+
+def check_nl_ring(asm):
+    """Raises AssertionError when a compiled nl_ring_kernel does not issue what its hand-counted waits assume.  Returns the
+    number of instantiations checked."""
+    seen = 0
+    for name, lines in _kernels(asm, "nl_ring_kernelI"):
+        m = re.search(r"nl_ring_kernelI([df])Lb[01]ELb[01]ELb[01]ELi(\d)ELb([01])E", name)
+        t, rd, satf = m.group(1), int(m.group(2)), m.group(3) == "1"
+        ni = 8 if t == "d" else 4
+        nstore = 10
+        nfull, nhead = (rd - 1) * ni + (rd - 2) * nstore, (rd - 1) * ni
+        nodes = _cfg(lines)
+        steady = [n for n, nd in nodes.items() if nd["wait"] == nfull and nd["ring_wait"]]
+        assert steady, (name, f"no s_waitcnt vmcnt({nfull})")
+        for n in steady:
+            r = _between_waits(nodes, n, nfull)
+            want_st = nstore + (1 if satf else 0)
+            # NI DMAs per level, + 1 for the pre-scan pair, + 1 static only: the default-policy / nt alternatives of the
+            # in_qsat DMA, which hipcc lays out as a fall-through behind an always-taken s_cbranch_execnz
+            assert ni <= r["dma_min_some"] and r["dma_max"] <= ni + 2, (name, "LDS-DMAs per level", r)
+            assert r["st"] == (want_st, want_st), (name, "stores per level", r)
+            assert r["ld"] == 0, (name, "ordinary loads inside the level loop", r)
+            assert r["waits"] <= {0, nhead, nfull}, (name, "vector-memory waits in the level loop", sorted(r["waits"]))
+        seen += 1
+    return seen
+
+
+def test_nl_ring_loop_matches_the_hand_counted_waits(nl_asm):
+    # T in {double, float} x EVAP x LIN x ring depth {3, 2} x SATF
+    assert check_nl_ring(nl_asm) == 32

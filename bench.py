@@ -15,6 +15,14 @@ Modes
   default      weak scaling: every rank owns `--cols` (65 536) fp64 columns of a global N*cols-column problem.
   --config 5   BASELINE.json configs[4]: ONE global problem of 4 194 304 fp32 columns split N ways
                (`cols = 4 194 304 / N`, "scaling": "strong", "dtype": "f32").
+  --config 3   BASELINE.json configs[2]: one step = one `TaylorTest.run` (/root/reference/src/cloudsc2_gt4py/physics/
+               tangent_linear/validation.py:150-181: saturation, cloudsc2_nl, state_increment, cloudsc2_tl, then ten times
+               perturbed_state + cloudsc2_nl + the norm) on 65 536 fp64 columns per GPU; the record carries the reference's
+               verdict string and, beside the headline (the reference's own call sequence, launched eagerly), the opt-in
+               variants: HIP-graph replay, perturbation fused into the NL loads, all step sizes in two launches.
+  --config 4   BASELINE.json configs[3]: one step = the timed call of run_symmetry_test.py:94-98
+               (`SymmetryTest(state, dt, enable_validation=False)`: saturation, state_increment, cloudsc2_tl, cloudsc2_ad);
+               the validated call that precedes it supplies the verdict.
 
 N > 1: one process per GPU.  Columns are independent, so there is NO data-path collective; RCCL is used only for
 the barrier, the max-over-ranks time and the final validation-norm all-reduce.  When `--gpus N > 1` is given to a
@@ -51,6 +59,12 @@ SAT_WORDS_PER_COL = 411          # 2 in, 1 out over 137 levels
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
 CONFIG5_COLUMNS = 4194304        # BASELINE.json configs[4]
 METRIC = "columns/sec at 137 levels fp64; achieved HBM GB/s vs MI355X roofline"
+METRIC_C3 = ("columns/sec through one TL Taylor-test run (run_taylor_test.py) at 137 levels fp64 (BASELINE configs[2]); "
+             "achieved HBM GB/s of the run's stencil sequence vs MI355X roofline")
+METRIC_C4 = ("columns/sec through one AD symmetry-test call (run_symmetry_test.py) at 137 levels fp64 (BASELINE configs[3]); "
+             "achieved HBM GB/s of the call's stencil sequence vs MI355X roofline")
+INC_WORDS_PER_COL = 4416         # state_increment: 16 in + 16 out over 138 levels
+PERT_WORDS_PER_COL = 6624        # perturbed_state: 32 in + 16 out over 138 levels
 METRIC_C5 = ("columns/sec at 137 levels fp32, 4 194 304 columns sharded over the GPUs (BASELINE configs[4]); "
              "achieved HBM GB/s vs MI355X roofline")
 
@@ -60,9 +74,18 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", type=int, choices=[2, 5], default=2,
+    ap.add_argument("--config", type=int, choices=[2, 3, 4, 5], default=2,
                     help="2 (default): BASELINE configs[1], 65 536 fp64 columns per GPU, weak scaling; "
-                         "5: BASELINE configs[4], 4 194 304 fp32 columns split over --gpus, strong scaling")
+                         "3: BASELINE configs[2], the TL Taylor test as the step; 4: BASELINE configs[3], the AD symmetry "
+                         "test as the step; 5: BASELINE configs[4], 4 194 304 fp32 columns split over --gpus, strong scaling")
+    ap.add_argument("--input", default="auto",
+                    help="--config 3 / 4: 'auto' = the reader path (data/input.h5 if present, else its 100-column stand-in, "
+                         "tiled to the columns: the configuration on which the reference's verdicts pass), 'synthetic' = "
+                         "distinct mixed-regime columns, or the path of an HDF5 input file")
+    ap.add_argument("--no-variants", action="store_true", help="--config 3 / 4: time the headline sequence only")
+    ap.add_argument("--tune-shifts-mb", default=None,
+                    help="dev: comma-separated whole-placement shifts (MB) for the placement tuner instead of 0/4/8/12 GB, "
+                         "with the arena allowed to grow to 96 GB (profiles/tuner_ab.sh)")
     ap.add_argument("--cols", type=int, default=None, help="columns per GPU (default 65536; --config 5: 4194304 / gpus)")
     ap.add_argument("--nlev", type=int, default=137)
     ap.add_argument("--precision", choices=["double", "single"], default=None)
@@ -85,6 +108,12 @@ def parse_args(argv=None):
     args = ap.parse_args(argv)
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
+    if args.tune_shifts_mb is not None:
+        try:
+            args.tune_shifts_mb = tuple(int(x) for x in args.tune_shifts_mb.split(","))
+            assert all(0 <= x <= 131072 for x in args.tune_shifts_mb) and args.tune_shifts_mb
+        except (ValueError, AssertionError):
+            ap.error("--tune-shifts-mb: a comma-separated list of shifts in MB (0 .. 131072)")
     if args.config == 5:
         if args.precision not in (None, "single"):
             ap.error("--config 5 is the fp32 configuration")
@@ -198,6 +227,17 @@ def cpu_baseline(cols: int, nz: int, np_dtype, budget_s: float = 8.0, hip_step=N
                                    "max_err_over_field_scale": worst, "rtol": tol["rtol"], "atol_rel": tol["atol_rel"],
                                    "passed": bad == 0,
                                    "what": "HIP saturation + cloudsc2_nl against oracle/cloudsc2_nl_omp.c on the same columns"}
+        # the same restatement on EVERY core this process may run on (north_star: "the node's host cores"), bounded too
+        all_threads = len(os.sched_getaffinity(0))
+        if all_threads > threads:
+            def c_step_all():
+                cloudsc2_c.saturation(F["in_ap"], F["in_t"], F["in_qsat"], ext, nthreads=all_threads)
+                cloudsc2_c.cloudsc2_nl(F, eta, dt, ext, nthreads=all_threads)
+
+            a_runs, a_el = loop(c_step_all, 4.0)
+            res["all_cores"] = {"value": cols * a_runs / a_el, "unit": "columns/s", "cores": all_threads,
+                                "sample": f"same restatement and columns on all {all_threads} cores of this process's "
+                                          f"affinity mask, {a_runs} runs in {a_el:.1f} s"}
         res.update(value=cols * c_runs / c_el, cores=threads,
                    sample=f"plain-C + OpenMP restatement (oracle/cloudsc2_nl_omp.c, {threads} threads, scalar libm, "
                           f"-O2), {what} float64, {c_runs} runs in {c_el:.1f} s, synthetic-parameters")
@@ -303,14 +343,19 @@ def dry_run(args, rank, world):
     eta = eta_levels(nz, dtype=np_dtype)
     t = torch.tensor([float(np.abs(s["f_t"]).sum()), float(rank * nx), float(eta.sum())], dtype=torch.float64)
     first = t.clone()
+    per_rank = torch.zeros(world, dtype=torch.float64)
+    per_rank[rank] = 0.001 * (rank + 1)                 # stand-in for this rank's elapsed time: rank r "took" r + 1 ms
     if dist.is_initialized():
         dist.barrier()
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dist.all_reduce(per_rank, op=dist.ReduceOp.SUM)  # the gather of the per-rank times (main() does the same)
         tm = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
     if rank == 0:
         res = base_record(args, world, nx, nz, value=None, ms_per_step=None,
                           ranks=dist.get_world_size() if dist.is_initialized() else None, backend="gloo (dry run)")
+        res["per_rank_ms"] = [1e3 * float(x) for x in per_rank]
+        res["per_rank_ms_min_max"] = [min(res["per_rank_ms"]), max(res["per_rank_ms"])]
         res.update(dry_run=True, data="dry run: no kernels were launched",
                    shard_check={"col0_sum": float(t[1]), "eta_sum_x_world": float(t[2]), "eta_sum": float(first[2])})
         print(json.dumps(res), flush=True)
@@ -349,6 +394,194 @@ def base_record(args, world, nx, nz, value, ms_per_step, ranks, backend):
     }
 
 
+# ------------------------------------------------------------------------------------------------ configs 3 / 4
+def harness_bench(args, rank, local_rank, world):
+    """BASELINE configs[2] / configs[3]: the TL Taylor test / the AD symmetry test as the timed step, through the
+    harness classes that mirror the reference's (`harness.TaylorTest`, `harness.SymmetryTest`) on the state the driver
+    mirror builds (`drivers._common.setup`: the reader path by default).  Same protocol as the headline: pre-warm >= 25 ms,
+    W warm-up steps, EXACTLY K steps between barrier + synchronize pairs, MAX over ranks."""
+    import argparse
+    import gc
+
+    import numpy as np
+    import torch
+
+    import __graft_entry__ as ge
+
+    ge.build()
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd import _lib
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.drivers import _common
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.harness import SymmetryTest, TaylorTest, taylor_verdict
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.stencils import finalize_exec_info
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if args.collective == "gloo":
+        raise SystemExit("--config 3 / 4: the harnesses all-reduce device tensors; the gloo rehearsal covers configs 2 / 5")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:
+        import torch.distributed as dist
+
+        with _StdoutToStderr():
+            dist.init_process_group("nccl", device_id=device)
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    taylor = args.config == 3
+    nx, nz = args.cols, args.nlev
+    wsize = 8 if args.precision == "double" else 4
+    ns = argparse.Namespace(backend="hip", enable_checks=False, enable_validation=True, num_cols=nx, num_runs=1,
+                            precision=args.precision, host_alias=None, output_csv_file=None, output_csv_file_stencils=None,
+                            input=args.input, atol=None, rtol=None)
+    with _StdoutToStderr():          # the set-up's notices must not land on stdout (ONE JSON line)
+        ctx = _common.setup(ns)
+    if ctx["nz"] != nz:
+        raise SystemExit(f"the input has {ctx['nz']} levels, --nlev says {nz}")
+    cfg, grid, state, dt, p = ctx["config"], ctx["grid"], ctx["state"], ctx["dt"], ctx["params"]
+    gcfg = cfg.gt4py_config
+    f2s = tuple(10 ** -(i + 1) for i in range(10))                     # run_taylor_test.py:76
+
+    def make(**kw):
+        common = dict(yoethf_params=p["yoethf"], yomcst_params=p["yomcst"], yrecldp_params=p["yrecldp"],
+                      yrephli_params=p["yrephli"], yrncl_params=p["yrncl"], yrphnc_params=p["yrphnc"],
+                      enable_checks=False, gt4py_config=gcfg, **kw)
+        if taylor:
+            return TaylorTest(grid, factor1=0.01, factor2s=f2s, kflag=1, lphylin=True, ldrain1d=False, **common)
+        return SymmetryTest(grid, factor=0.01, kflag=1, lphylin=True, ldrain1d=False, **common)
+
+    sat_b, nl_b, tl_b = SAT_WORDS_PER_COL, NL_WORDS_PER_COL, TLAD_WORDS_PER_COL
+    pnl_words = 2 * 2193 + 1374                    # perturbed NL run fused: 32 fields read, 10 written (or 10 references read)
+    if taylor:
+        seq_words = {"plain": sat_b + nl_b + INC_WORDS_PER_COL + tl_b + 10 * (PERT_WORDS_PER_COL + nl_b),     # 117 438
+                     "fused": sat_b + nl_b + INC_WORDS_PER_COL + tl_b + 10 * pnl_words,
+                     "fused_all": sat_b + nl_b + INC_WORDS_PER_COL + tl_b + 2 * pnl_words}
+        variants = [("graph", dict(graph=True), "plain"), ("fused", dict(fused=True), "fused"),
+                    ("fused_graph", dict(fused=True, graph=True), "fused"), ("fused_all", dict(fused_all=True), "fused_all"),
+                    ("fused_all_graph", dict(fused_all=True, graph=True), "fused_all")]
+        what = ("saturation + cloudsc2_nl + state_increment + cloudsc2_tl + 10 x (perturbed_state + cloudsc2_nl) + the "
+                "norms' reductions (tangent_linear/validation.py:150-181)")
+    else:
+        seq_words = {"plain": sat_b + INC_WORDS_PER_COL + tl_b + tl_b}                                         # 19 095
+        variants = [("graph", dict(graph=True), "plain")]
+        what = "saturation + state_increment + cloudsc2_tl + cloudsc2_ad (adjoint/validation.py:135-151, validation off)"
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def run_window(h, steps, warmup):
+        """(seconds for `steps` steps, verdict info) of harness `h`; the first call allocates and - Taylor - yields the norms"""
+        if taylor:
+            norms = h.run(state, dt)
+            ok, verdict = taylor_verdict(norms)
+            info = {"norms": [float(x) for x in norms], "verdict": verdict, "passed": bool(ok)}
+            step = lambda: h.run(state, dt)  # noqa: E731
+        else:
+            with _StdoutToStderr():
+                ok = h(state, dt, enable_validation=True)
+            info = {"verdict": "The symmetry test passed. HOORAY!" if ok else "The symmetry test failed.",
+                    "passed": bool(ok), **(h.last or {})}
+            step = lambda: h(state, dt, enable_validation=False)  # noqa: E731
+        step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        one = max(time.perf_counter() - t1, 1e-4)
+        for _ in range(max(0, int(0.025 / one) + 1 - warmup)):      # >= 25 ms of the same work right before the warm-up
+            step()
+        for _ in range(warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        barrier()
+        return el, info
+
+    gc.collect()
+    gc.disable()
+    head = make()
+    elapsed, info = run_window(head, args.steps, args.warmup)
+    per_rank_ms = [1e3 * elapsed / args.steps]
+    if dist is not None:
+        t = torch.zeros(world, dtype=torch.float64, device=device)
+        t[rank] = elapsed
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        per_rank_ms = [1e3 * float(x) / args.steps for x in t.cpu()]
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    gc.enable()
+
+    # per-stencil device times of ONE instrumented step (HIP events around every stencil call)
+    gcfg.exec_info = {}
+    if taylor:
+        head.run(state, dt)
+    else:
+        head(state, dt, enable_validation=False)
+    finalize_exec_info(gcfg.exec_info)
+    kernels = {k: {"ncalls": v["ncalls"], "device_ms": 1e3 * v.get("total_run_time", 0.0)}
+               for k, v in gcfg.exec_info.items() if isinstance(v, dict) and "ncalls" in v}
+    gcfg.exec_info = None
+    last_kernel = _lib.last_kernel()
+
+    var_out = {}
+    if not args.no_variants and world == 1:
+        for name, kw, seq in variants:
+            try:
+                h = make(**kw)
+                el, vinfo = run_window(h, args.steps, args.warmup)
+                ms = 1e3 * el / args.steps
+                nbytes = seq_words[seq] * wsize * nx
+                var_out[name] = {"ms_per_step": ms, "value": nx * args.steps / el, "unit": "columns/s",
+                                 "bytes_per_step": nbytes, "achieved_GBs": nbytes / (ms * 1e-3) / 1e9,
+                                 "frac_of_8TBs": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, **vinfo}
+                del h
+                torch.cuda.empty_cache()
+            except Exception as exc:  # noqa: BLE001 - a variant must not cost the headline line
+                var_out[name] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+                torch.cuda.empty_cache()
+
+    if rank == 0:
+        total = nx * world
+        ms = 1e3 * elapsed / args.steps
+        nbytes = seq_words["plain"] * wsize * nx
+        res = base_record(args, world, nx, nz, value=total * args.steps / elapsed, ms_per_step=ms,
+                          ranks=dist.get_world_size() if dist is not None else None,
+                          backend="nccl (RCCL)" if dist is not None else "none (single process)")
+        res["metric"] = METRIC_C3 if taylor else METRIC_C4
+        res["data"] = ctx["source"]
+        res["config"]["workload"] = (
+            f"BASELINE configs[{2 if taylor else 3}]: CLOUDSC2-{'TL Taylor test' if taylor else 'AD symmetry test'} "
+            f"({'run_taylor_test.py' if taylor else 'run_symmetry_test.py'}), {nx} cols x {nz} lev per GPU, {args.precision}, "
+            f"{world} GPU(s); one step = {what}")
+        res["config"]["input"] = args.input
+        res["per_rank_ms"] = per_rank_ms
+        res["per_rank_ms_min_max"] = [min(per_rank_ms), max(per_rank_ms)]
+        res["verdict"] = info
+        ach = nbytes / (ms * 1e-3) / 1e9
+        res["roofline"] = {"kernel": "sequence: " + what, "last_kernel": last_kernel, "bound": "hbm", "achieved": ach,
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                           "bytes_per_launch": nbytes, "bytes_per_column": seq_words["plain"] * wsize,
+                           "avg_launch_ms": ms, "columns": nx, "dtype": "f64" if wsize == 8 else "f32",
+                           "what": "algorithmic bytes of the step's whole stencil sequence (SURVEY.md 8d per-stencil "
+                                   "figures; the norms' reductions are not counted) / the step's wall time, host side included",
+                           "stencils_one_step": kernels,
+                           "device_ms_one_step": sum(k["device_ms"] for k in kernels.values())}
+        res["variants"] = var_out
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+
 # ------------------------------------------------------------------------------------------------ main
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else list(argv)
@@ -363,6 +596,8 @@ def main(argv=None):
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
     if args.dry_run:
         return dry_run(args, rank, world)
+    if args.config in (3, 4):
+        return harness_bench(args, rank, local_rank, world)
 
     import numpy as np
     import torch
@@ -432,8 +667,16 @@ def main(argv=None):
     F = None
     if args.placement == "tuned":
         try:
-            F, rep = storage.tune_placement(nx, nz, np_dtype, device, order, sources, step_on)
+            tkw = {}
+            if args.tune_shifts_mb:      # dev A/B of the shift range: explicit, validated (was an environment switch)
+                tkw = dict(shifts_mb=args.tune_shifts_mb, max_arena_bytes=96 << 30, max_shift_spans=1e9)
+            t_tune = time.perf_counter()
+            F, rep = storage.tune_placement(nx, nz, np_dtype, device, order, sources, step_on, **tkw)
+            torch.cuda.synchronize()
             placement.update(rep)
+            # what the opt-in costs: the arena kept alive for the state (the 26 fields themselves are 1.9 GB at the
+            # headline size) and the wall time of the calibration, outside the timed window
+            placement.update(arena_GB=rep.get("arena_bytes", 0) / 1e9, tuning_s=time.perf_counter() - t_tune)
         except RuntimeError as exc:      # e.g. a shared device without room for the arena: say so, run on plain allocations
             placement = {"mode": "separate", "tune_error": f"{type(exc).__name__}: {exc}"[:300]}
             torch.cuda.empty_cache()
@@ -506,7 +749,8 @@ def main(argv=None):
         b.record()
         torch.cuda.synchronize()
         nl_train_ms = a.elapsed_time(b) / reps
-        # this box's streaming-copy ceiling (1 GiB device-to-device copy, read + write bytes)
+        # a 1 GiB torch device-to-device copy on this box (read + write bytes), for orientation only: it is SLOWER than the
+        # NL kernel's own stream rate, i.e. not a ceiling
         src = torch.empty(1 << 27, dtype=torch.float64, device=device)
         dst = torch.empty_like(src)
         for _ in range(2):
@@ -621,10 +865,37 @@ def main(argv=None):
     elapsed = time.perf_counter() - t0      # this rank's K steps, from the common start to its own completion
     barrier()                               # closing bracket; the job time is the MAX over ranks taken below
     gc.enable()
+    per_rank_ms = [1e3 * elapsed / args.steps]
     if dist is not None:
+        # every rank's own time for its K steps (a straggler must be visible in the record), then the job time = MAX
+        t = torch.zeros(world, dtype=torch.float64, device=red_device)
+        t[rank] = elapsed
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        per_rank_ms = [1e3 * float(x) / args.steps for x in t.cpu()]
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # the same step on the DEFAULT placement (one torch allocation per field - what `storage.zeros` and the drivers give a
+    # caller who does not opt into the tuner), timed right after the headline window on a copy of the state: reported
+    # beside `value` so that the record never describes only the opt-in path
+    default_placement = None
+    if placement.get("mode") == "tuned" and not args.no_roofline_events and nx <= 1 << 20:
+        try:
+            Fd = {k: storage.from_klayout(storage.klayout(v).clone(), np_dtype, device) for k, v in F.items()}
+            for _ in range(max(70, args.warmup)):
+                step_on(Fd)
+            torch.cuda.synchronize()
+            td = time.perf_counter()
+            for _ in range(args.steps):
+                step_on(Fd)
+            torch.cuda.synchronize()
+            td = time.perf_counter() - td
+            default_placement = {"ms_per_step": 1e3 * td / args.steps, "value_this_rank": nx * args.steps / td}
+            del Fd
+        except RuntimeError as exc:
+            default_placement = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+            torch.cuda.empty_cache()
 
     # the same step as ONE launch (build extension: saturation evaluated inside the NL kernel, stencil
     # `cloudsc2_nl_saturation`); reported beside the headline, never as `value`
@@ -681,12 +952,22 @@ def main(argv=None):
         if rehearsal and dist is not None:
             res["rccl_ranks"], res["rehearsal_ranks"] = None, dist.get_world_size()
         res["prewarm_steps"] = prewarm
+        res["per_rank_ms"] = per_rank_ms
+        res["per_rank_ms_min_max"] = [min(per_rank_ms), max(per_rank_ms)]
         res["placement"] = placement
+        if default_placement is not None:
+            # rank 0's figure on separate allocations, scaled to the job (weak scaling: every rank does the same work)
+            if "value_this_rank" in default_placement:
+                res["value_default_placement"] = default_placement["value_this_rank"] * world
+                res["ms_per_step_default_placement"] = default_placement["ms_per_step"]
+            else:
+                res["value_default_placement"] = None
+                res["default_placement_error"] = default_placement.get("error")
         res["outputs_finite"] = finite
         res["validation_norm"] = dict(zip(NL_OUT, norm))
         if nl_ms is not None:
             res["roofline"] = roofline_entry(nl_kernel_name, NL_WORDS_PER_COL, wsize, nx, args.precision, nl_ms,
-                                             avg_launch_ms_back_to_back=nl_train_ms, box_copy_ceiling_GBs=copy_gbs,
+                                             avg_launch_ms_back_to_back=nl_train_ms, box_torch_copy_GBs=copy_gbs,
                                              launch_window=nl_window)
         res.update(extra)
         if fused is not None:

@@ -28,6 +28,9 @@ EXPORTED_SYMBOLS = (
     "cloudsc2_nl_f64", "cloudsc2_nl_f32",
     "cloudsc2_nl_fused_f64", "cloudsc2_nl_fused_f32",
     "cloudsc2_nl_taylor_blocks", "cloudsc2_nl_taylor_f64", "cloudsc2_nl_taylor_f32",
+    "cloudsc2_nl_taylor_multi_f64", "cloudsc2_nl_taylor_multi_f32",
+    "cloudsc2_field_sums_blocks", "cloudsc2_field_sums_f64", "cloudsc2_field_sums_f32",
+    "cloudsc2_column_dots_f64", "cloudsc2_column_dots_f32",
     "cloudsc2_tl_f64", "cloudsc2_tl_f32",
     "cloudsc2_ad_f64", "cloudsc2_ad_f32",
     "cloudsc2_saturation_f64", "cloudsc2_saturation_f32",
@@ -56,6 +59,8 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.cloudsc2_device_count.argtypes = []
     lib.cloudsc2_nl_taylor_blocks.restype = c_int32
     lib.cloudsc2_nl_taylor_blocks.argtypes = [c_int32]
+    lib.cloudsc2_field_sums_blocks.restype = c_int32
+    lib.cloudsc2_field_sums_blocks.argtypes = [c_int32, c_int32]
     for sfx, real in (("f64", c_double), ("f32", c_float)):
         del real  # device pointers travel as integers (void*), never dereferenced on the host
         parr = POINTER(c_void_p)
@@ -69,6 +74,15 @@ def _declare(lib: ctypes.CDLL) -> None:
         f = getattr(lib, f"cloudsc2_nl_taylor_{sfx}")
         f.restype = c_int32
         f.argtypes = common + [parr, parr, c_double, c_void_p, parr, c_void_p, c_double, c_void_p]
+        f = getattr(lib, f"cloudsc2_nl_taylor_multi_{sfx}")
+        f.restype = c_int32
+        f.argtypes = common + [parr, parr, c_int32, POINTER(c_double), c_void_p, parr, c_void_p, c_double, c_void_p]
+        f = getattr(lib, f"cloudsc2_field_sums_{sfx}")
+        f.restype = c_int32
+        f.argtypes = [c_int32, c_int32, c_int64, c_int32, parr, parr, c_void_p, c_void_p]
+        f = getattr(lib, f"cloudsc2_column_dots_{sfx}")
+        f.restype = c_int32
+        f.argtypes = [c_int32, c_int32, c_int64, c_int32, parr, parr, c_void_p, c_int32, c_void_p]
         for name in ("tl", "ad"):
             f = getattr(lib, f"cloudsc2_{name}_{sfx}")
             f.restype = c_int32

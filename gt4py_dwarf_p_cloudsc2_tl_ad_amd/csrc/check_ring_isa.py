@@ -1,0 +1,202 @@
+"""Build-time guard of the hand-counted `s_waitcnt vmcnt(N)` in the LDS-ring kernels (cloudsc2_nl.hip, cloudsc2_tl.hip).
+
+The ring kernels wait for "all but the N youngest vector-memory operations"; N is counted by hand from what the level loop
+issues (NI LDS-DMAs + the level's stores).  That count is only right for the code hipcc actually emitted, so it is checked
+on the compiled gfx950 assembly (no GPU needed):
+
+  * tl_ring_kernel (two slots per wave, EXACT wait `vmcnt(NI + 20)`): the loop body around the wait holds exactly NI
+    `global_load_lds_dwordx4`, 20 `global_store`, no ordinary load, and no vector-memory wait hipcc added on its own;
+  * nl_ring_kernel (three / two slots, wait one level of stores stricter than exact): hipcc multiplies the level body per
+    cache-policy path (the in_qsat DMA, the optional pre-scan DMA), so lines cannot simply be counted; the kernel's
+    control-flow graph is walked instead: on EVERY static path from one steady-state ring wait to the next there are
+    >= NSTORE stores, the paths that issue any DMA issue >= NI of them, there is no ordinary load and no vector-memory
+    wait other than the three hand-written ones (NFULL, NHEAD, 0).
+
+Used by tests/test_ring_isa.py (CPU suite) and by `__graft_entry__.build()` whenever it really recompiles the library, so a
+library built by a different hipcc cannot ship with a wrong count.  `python check_ring_isa.py` runs it by hand."""
+from __future__ import annotations
+
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+CSRC = os.path.dirname(os.path.abspath(__file__))
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+def compile_to_asm(src: str, out_dir: str) -> str:
+    out = os.path.join(out_dir, src + ".s")
+    subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S", src, "-o", out],
+                   cwd=CSRC, check=True, capture_output=True)
+    with open(out) as fh:
+        return fh.read()
+
+
+def _kernels(asm, prefix):
+    for m in re.finditer(r"^(_ZN3cs2\w+):", asm, flags=re.M):
+        name = m.group(1)
+        if prefix in name:
+            end = asm.index(".end_amdhsa_kernel", m.end()) if ".end_amdhsa_kernel" in asm[m.end():] else len(asm)
+            yield name, asm[m.end():end].split("\n")
+
+
+def _innermost_loop_around(lines, idx, outermost=False):
+    labels = {m.group(1): i for i, l in enumerate(lines) if (m := re.match(r"(\.LBB\d+_\d+):", l.strip()))}
+    best = None
+    for i, l in enumerate(lines):
+        m = re.match(r"\s*s_c?branch\w* (\.LBB\d+_\d+)", l)
+        if m and m.group(1) in labels and labels[m.group(1)] <= idx <= i:
+            smaller = best is None or (i - labels[m.group(1)]) < (best[1] - best[0])
+            if best is None or smaller != outermost:
+                best = (labels[m.group(1)], i)
+    return best
+
+
+def check_tl_ring(asm):
+    """Raises AssertionError when a compiled tl_ring_kernel does not match its hand-counted wait; returns the number of
+    instantiations checked."""
+    seen = 0
+    for tname, ni in (("d", 16), ("f", 8)):
+        expected = ni + 20            # two slots per wave: (RD-1) x (NI DMAs + 20 stores)
+        for name, lines in _kernels(asm, "tl_ring_kernelI" + tname):
+            waits = [i for i, l in enumerate(lines) if re.search(rf"s_waitcnt vmcnt\({expected}\)\s*$", l)]
+            assert len(waits) == 1, (name, "steady-state wait not found exactly once", len(waits))
+            lo, hi = _innermost_loop_around(lines, waits[0])
+            body = lines[lo:hi + 1]
+            stores = sum("global_store" in l for l in body)
+            dmas = sum("global_load_lds_dwordx4" in l for l in body)
+            plain_loads = sum(bool(re.search(r"global_load_dword", l)) for l in body)
+            assert stores == 20 and dmas == ni and plain_loads == 0, (name, stores, dmas, plain_loads)
+            vm_waits = [re.search(r"vmcnt\((\d+)\)", l).group(1) for l in body if "s_waitcnt" in l and "vmcnt" in l]
+            # the loop's only vector-memory waits: the counted one, the tail's drain (0), the second half's no-op (63) and -
+            # unless hipcc peeled the first iteration - the head's (NI: no stores counted yet)
+            assert set(vm_waits) - {str(ni)} == {"0", "63", str(expected)} and vm_waits.count("0") == 1, (name, vm_waits)
+            seen += 1
+    return seen
+
+
+def _cfg(lines):
+    """Nodes of a kernel's control-flow graph, split at labels, branches and vector-memory waits.  Every node is
+    (kind counts, wait value or None, successors)."""
+    starts = {0}
+    label_at = {}
+    for i, l in enumerate(lines):
+        t = l.strip()
+        if (m := re.match(r"(\.LBB\d+_\d+):", t)):
+            starts.add(i)
+            label_at[m.group(1)] = i
+        if re.match(r"s_c?branch|s_endpgm", t):
+            starts.add(i + 1)
+        if t.startswith("s_waitcnt") and "vmcnt" in t:
+            starts.add(i)
+            starts.add(i + 1)
+    order = sorted(x for x in starts if x < len(lines))
+    nodes = {}
+    for a, b in zip(order, order[1:] + [len(lines)]):
+        body = [l.strip() for l in lines[a:b]]
+        wait = None
+        if body and body[0].startswith("s_waitcnt") and "vmcnt" in body[0]:
+            wait = int(re.search(r"vmcnt\((\d+)\)", body[0]).group(1))
+        succ = []
+        last = next((t for t in reversed(body) if t and not t.startswith(";")), "")
+        m = re.match(r"s_(c?)branch\w* (\.LBB\d+_\d+)", last)
+        if m:
+            succ.append(label_at[m.group(2)])
+            if m.group(1):
+                succ.append(b)
+        elif not last.startswith("s_endpgm"):
+            succ.append(b)
+        # the hand-written ring waits are the ones fused with the slot's LDS reads in one asm statement
+        ring_wait = wait is not None and b < len(lines) and lines[b].strip().startswith("ds_read_b")
+        nodes[a] = dict(ring_wait=ring_wait, dma=sum("global_load_lds" in t for t in body), st=sum(t.startswith("global_store") for t in body),
+                        ld=sum(bool(re.match(r"global_load_dword", t)) for t in body), wait=wait,
+                        succ=[x for x in succ if x < len(lines)])
+    return nodes
+
+
+def _between_waits(nodes, start, nfull):
+    """Over all static paths from the ring wait `start` to the next steady-state ring wait (paths end at ANY vector-memory
+    wait; only those ending at a vmcnt(NFULL) ring wait count): min / max stores, max ordinary loads, max LDS-DMAs, the min
+    of LDS-DMAs over the paths that issue at least one (the static graph also contains the infeasible combination
+    "`more` false at the issue, true at the wait" - the two tests are the same uniform condition - which issues none), and
+    the set of wait values met."""
+    import sys
+
+    sys.setrecursionlimit(20000)
+    INF = 10 ** 9
+    seen_waits = set()
+    memo = {}
+    BUSY = object()
+
+    def walk(n):
+        if n in memo:
+            # a node still being expanded = a static cycle through the level loop that bypasses all three waits (the same
+            # infeasible combination of the uniform `more` tests): ignored
+            return None if memo[n] is BUSY else memo[n]
+        nd = nodes[n]
+        if nd["wait"] is not None:
+            seen_waits.add(nd["wait"])
+            memo[n] = dict(st=(0, 0), ld=0, dma_max=0, dma_min_any=0, dma_min_some=INF) \
+                if (nd["wait"] == nfull and nd["ring_wait"]) else None
+            return memo[n]
+        memo[n] = BUSY
+        res = [r for r in (walk(s) for s in nd["succ"]) if r is not None]
+        if not res:
+            memo[n] = None
+            return None
+        d = nd["dma"]
+        any_min = min(r["dma_min_any"] for r in res)
+        memo[n] = dict(st=(nd["st"] + min(r["st"][0] for r in res), nd["st"] + max(r["st"][1] for r in res)),
+                       ld=nd["ld"] + max(r["ld"] for r in res), dma_max=d + max(r["dma_max"] for r in res),
+                       dma_min_any=d + any_min,
+                       dma_min_some=(d + any_min) if d > 0 else min(r["dma_min_some"] for r in res))
+        return memo[n]
+
+    res = [r for r in (walk(s) for s in nodes[start]["succ"]) if r is not None]
+    assert res, "the steady-state wait is not inside a loop"
+    return dict(st=(min(r["st"][0] for r in res), max(r["st"][1] for r in res)), ld=max(r["ld"] for r in res),
+                dma_max=max(r["dma_max"] for r in res), dma_min_some=min(r["dma_min_some"] for r in res),
+                waits=seen_waits)
+
+
+def check_nl_ring(asm):
+    """Raises AssertionError when a compiled nl_ring_kernel does not issue what its hand-counted waits assume.  Returns the
+    number of instantiations checked."""
+    seen = 0
+    for name, lines in _kernels(asm, "nl_ring_kernelI"):
+        m = re.search(r"nl_ring_kernelI([df])Lb[01]ELb[01]ELb[01]ELi(\d)ELb([01])E", name)
+        t, rd, satf = m.group(1), int(m.group(2)), m.group(3) == "1"
+        ni = 8 if t == "d" else 4
+        nstore = 10
+        nfull, nhead = (rd - 1) * ni + (rd - 2) * nstore, (rd - 1) * ni
+        nodes = _cfg(lines)
+        steady = [n for n, nd in nodes.items() if nd["wait"] == nfull and nd["ring_wait"]]
+        assert steady, (name, f"no s_waitcnt vmcnt({nfull})")
+        for n in steady:
+            r = _between_waits(nodes, n, nfull)
+            want_st = nstore + (1 if satf else 0)
+            # NI DMAs per level, + 1 for the pre-scan pair, + 1 static only: the default-policy / nt alternatives of the
+            # in_qsat DMA, which hipcc lays out as a fall-through behind an always-taken s_cbranch_execnz
+            assert ni <= r["dma_min_some"] and r["dma_max"] <= ni + 2, (name, "LDS-DMAs per level", r)
+            assert r["st"] == (want_st, want_st), (name, "stores per level", r)
+            assert r["ld"] == 0, (name, "ordinary loads inside the level loop", r)
+            assert r["waits"] <= {0, nhead, nfull}, (name, "vector-memory waits in the level loop", sorted(r["waits"]))
+        seen += 1
+    return seen
+
+
+def check_all(out_dir=None) -> dict:
+    """Compile both ring sources to assembly and check every instantiation; raises AssertionError on a mismatch."""
+    with tempfile.TemporaryDirectory() as tmp:
+        d = out_dir or tmp
+        n_tl = check_tl_ring(compile_to_asm("cloudsc2_tl.hip", d))
+        n_nl = check_nl_ring(compile_to_asm("cloudsc2_nl.hip", d))
+    assert n_tl == 8 and n_nl == 32, (n_tl, n_nl)      # T x REG x EVAP; T x EVAP x LIN x depth {3, 2} x SATF
+    return {"tl_ring_kernel": n_tl, "nl_ring_kernel": n_nl}
+
+
+if __name__ == "__main__":
+    print("ring ISA check:", check_all())
+    sys.exit(0)

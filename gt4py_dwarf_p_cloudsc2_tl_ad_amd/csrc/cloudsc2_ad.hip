@@ -1070,7 +1070,8 @@ int launch_ad(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
     if (!fits_u32_offsets<T>(nz, ls)) return -2;
     if (smem > size_t(160) * 1024) return -2;
     int dev = 0;
-    if (smem > size_t(64) * 1024 && hipGetDevice(&dev) != hipSuccess) return -1;
+    if (smem > size_t(64) * 1024)
+        if (const int rc = current_device(dev)) return rc;
     const bool reg = p.LREGCL != 0;
     const bool fix = p.AD_TRAJ_FIX != 0;
     // cache-resident turnaround (CS2_AD_KEEP_MB): bottom levels whose 18 re-read words per column fit the budget
@@ -1084,13 +1085,8 @@ int launch_ad(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
     do {                                                                                                               \
         auto kern = ad_kernel<T, R, F, E>;                                                                             \
         if (smem > size_t(64) * 1024) { /* > 64 KB of dynamic LDS needs the opt-in: once per instantiation and device */ \
-            static size_t attr_set[64] = {};                                                                           \
-            if (attr_set[dev & 63] < smem) {                                                                           \
-                if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                           \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, int(smem)) != hipSuccess)          \
-                    return -1;                                                                                         \
-                attr_set[dev & 63] = smem;                                                                             \
-            }                                                                                                          \
+            static std::atomic<size_t> attr_set[kMaxDevices] = {};                                                     \
+            if (!lds_opt_in(kern, attr_set, dev, smem)) return -1;                                                     \
         }                                                                                                              \
         hipLaunchKernelGGL(kern, grid, block, smem, stream, e, kc, xk, nx, nz, ls, ci, ca, eta, co, coa, tdt, keep_from);         \
     } while (0)

@@ -150,13 +150,124 @@ int launch_perturb(int nx, int nz, int64_t ls, const T* const* in, const T* cons
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+
+// ---- validation-norm reductions (build extensions behind cloudsc2_field_sums_* / cloudsc2_column_dots_*) ---------------
+// The harnesses of the reference reduce whole fields on the host with NumPy: TaylorTest.get_field_norm forms
+// sum(field_nl_p - field_nl) and sum(field_tl) per output field (tangent_linear/validation.py:250-261), SymmetryTest
+// forms per-column sums over levels of products of fields (adjoint/validation.py:167-215).  Done with torch those are
+// two to three kernels and a temporary per field (200 small launches per Taylor run); here ONE launch handles up to
+// kSumFields fields / pairs.  Arithmetic as the reference: the difference (product) is formed in the field type, the
+// accumulation is in double.
+constexpr int kSumFields = 16;
+constexpr int kSumLevels = 18;   // levels per workgroup of field_sums_kernel (138 levels -> 8 chunks)
+
+template <typename T>
+__global__ void __launch_bounds__(kAuxBlock)
+field_sums_kernel(int nx, int nlev, int64_t ls, int nf, CPtrs<T, kSumFields> a, CPtrs<T, kSumFields> b, int has_b,
+                  double* __restrict__ partials) {
+    const int col = blockIdx.x * kAuxBlock + threadIdx.x;
+    const int k0 = blockIdx.y * kSumLevels;
+    const int k1 = k0 + kSumLevels < nlev ? k0 + kSumLevels : nlev;
+    double acc[kSumFields];
+#pragma unroll
+    for (int f = 0; f < kSumFields; ++f) acc[f] = 0.0;
+    if (col < nx) {
+        for (int k = k0; k < k1; ++k) {
+            const int64_t i = int64_t(k) * ls + col;
+#pragma unroll
+            for (int f = 0; f < kSumFields; ++f)
+                if (f < nf) {   // uniform
+                    T v = ntload(a.p[f] + i);
+                    if (has_b) v = v - ntload(b.p[f] + i);
+                    acc[f] += double(v);
+                }
+        }
+    }
+    __shared__ double s_red[kAuxBlock / 64][kSumFields];
+#pragma unroll
+    for (int f = 0; f < kSumFields; ++f) {
+        double v = acc[f];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6][f] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < nf) {
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < kAuxBlock / 64; ++w) v += s_red[w][threadIdx.x];
+        partials[(size_t(blockIdx.y) * gridDim.x + blockIdx.x) * size_t(nf) + threadIdx.x] = v;
+    }
+}
+
+int field_sums_blocks(int nx, int nlev) {
+    if (nx <= 0 || nlev <= 0) return 0;
+    return ((nx + kAuxBlock - 1) / kAuxBlock) * ((nlev + kSumLevels - 1) / kSumLevels);
+}
+
+template <typename T>
+int launch_field_sums(int nx, int nlev, int64_t ls, int nf, const T* const* a, const T* const* b, double* partials,
+                      hipStream_t stream) {
+    CPtrs<T, kSumFields> ca, cb;
+    for (int i = 0; i < kSumFields; ++i) {
+        ca.p[i] = i < nf ? a[i] : nullptr;
+        cb.p[i] = (b && i < nf) ? b[i] : nullptr;
+    }
+    const dim3 grid((nx + kAuxBlock - 1) / kAuxBlock, (nlev + kSumLevels - 1) / kSumLevels), block(kAuxBlock);
+    hipLaunchKernelGGL((field_sums_kernel<T>), grid, block, 0, stream, nx, nlev, ls, nf, ca, cb, b ? 1 : 0, partials);
+    note_kernel("cs2::field_sums_kernel");
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// out[col] = sum over pairs p and levels k of a_p[k][col] * b_p[k][col]  (b == a: squares), one lane per column
+template <typename T>
+__global__ void __launch_bounds__(kAuxBlock)
+column_dots_kernel(int nx, int nlev, int64_t ls, int np, CPtrs<T, kSumFields> a, CPtrs<T, kSumFields> b,
+                   double* __restrict__ out, int accumulate) {
+    const int col = blockIdx.x * kAuxBlock + threadIdx.x;
+    if (col >= nx) return;
+    double acc = 0.0;
+    for (int k = 0; k < nlev; ++k) {
+        const int64_t i = int64_t(k) * ls + col;
+        T va[kSumFields], vb[kSumFields];
+#pragma unroll
+        for (int f = 0; f < kSumFields; ++f)
+            if (f < np) {   // uniform
+                va[f] = ntload(a.p[f] + i);
+                vb[f] = a.p[f] == b.p[f] ? va[f] : ntload(b.p[f] + i);
+            }
+#pragma unroll
+        for (int f = 0; f < kSumFields; ++f)
+            if (f < np) acc += double(va[f]) * double(vb[f]);
+    }
+    out[col] = accumulate ? out[col] + acc : acc;
+}
+
+template <typename T>
+int launch_column_dots(int nx, int nlev, int64_t ls, int np, const T* const* a, const T* const* b, double* out,
+                       int accumulate, hipStream_t stream) {
+    CPtrs<T, kSumFields> ca, cb;
+    for (int i = 0; i < kSumFields; ++i) {
+        ca.p[i] = i < np ? a[i] : nullptr;
+        cb.p[i] = i < np ? b[i] : nullptr;
+    }
+    const dim3 grid((nx + kAuxBlock - 1) / kAuxBlock), block(kAuxBlock);
+    hipLaunchKernelGGL((column_dots_kernel<T>), grid, block, 0, stream, nx, nlev, ls, np, ca, cb, out, accumulate);
+    note_kernel("cs2::column_dots_kernel");
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 #define CS2_INST(T)                                                                                           \
     template int launch_saturation<T>(const Cloudsc2Params&, int, int, int64_t, const T*, const T*, T*,      \
                                       hipStream_t);                                                           \
     template int launch_increment<T>(const Cloudsc2Params&, int, int, int64_t, const T* const*, T* const*,   \
                                      double, hipStream_t);                                                    \
     template int launch_perturb<T>(int, int, int64_t, const T* const*, const T* const*, T* const*, double,   \
-                                   hipStream_t);
+                                   hipStream_t);                                                              \
+    template int launch_field_sums<T>(int, int, int64_t, int, const T* const*, const T* const*, double*,     \
+                                      hipStream_t);                                                           \
+    template int launch_column_dots<T>(int, int, int64_t, int, const T* const*, const T* const*, double*,    \
+                                       int, hipStream_t);
 CS2_INST(double)
 CS2_INST(float)
 #undef CS2_INST

@@ -11,6 +11,14 @@ template <typename T>
 int launch_nl(const Cloudsc2Params&, int, int, int64_t, const T* const*, const T*, T* const*, double, hipStream_t,
               const T* const*, double, T*, double*);
 template <typename T>
+int launch_nl_taylor_multi(const Cloudsc2Params&, int, int, int64_t, const T* const*, const T* const*, int, const double*,
+                           const T*, const T* const*, double*, double, hipStream_t);
+int field_sums_blocks(int, int);
+template <typename T>
+int launch_field_sums(int, int, int64_t, int, const T* const*, const T* const*, double*, hipStream_t);
+template <typename T>
+int launch_column_dots(int, int, int64_t, int, const T* const*, const T* const*, double*, int, hipStream_t);
+template <typename T>
 int launch_tl(const Cloudsc2Params&, int, int, int64_t, const T* const*, const T* const*, const T*, T* const*,
               T* const*, double, hipStream_t);
 template <typename T>
@@ -57,9 +65,10 @@ int check_ptrs(const char* fn, const char* what, const T* const* arr, int n) {
 
 int launched(const char* fn, int rc) {
     if (rc == 0) return CLOUDSC2_OK;
-    if (rc == -2)   // the launchers' one refusal: a field larger than 4 GiB (the kernels address it with 32-bit byte offsets)
+    if (rc == -2)   // the launchers' refusals: a field of 4 GiB or more (32-bit byte offsets), or a device ordinal >= 64
         return fail(CLOUDSC2_E_UNSUPPORTED,
-                    "%s: (nz+1) * lev_stride * sizeof(element) must be < 2^32 bytes per field - split the columns into blocks", fn);
+                    "%s: (nz+1) * lev_stride * sizeof(element) must be < 2^32 bytes per field - split the columns into blocks "
+                    "(or: HIP device ordinal >= 64, LDS demand beyond one CU)", fn);
     return fail(CLOUDSC2_E_LAUNCH, "%s: HIP launch failed: %s", fn, hipGetErrorString(hipPeekAtLastError()));
 }
 
@@ -119,6 +128,52 @@ int nl_taylor_impl(const char* fn, const Cloudsc2Params* p, int32_t nx, int32_t 
     for (int i = 0; i < NL_NUM_OUT; ++i) refs[i] = const_cast<T*>(ref_out[i]);
     return launched(fn, cs2::launch_nl<T>(*p, nx, nz, ls, in, eta, refs, dt, static_cast<hipStream_t>(stream), in_i, pf,
                                           nullptr, partials));
+}
+
+// The Taylor test's perturbed runs, several step sizes per launch (build extension): see include/cloudsc2_hip.h.
+template <typename T>
+int nl_taylor_multi_impl(const char* fn, const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls, const T* const* in,
+                         const T* const* in_i, int32_t nf, const double* pf, const T* eta, const T* const* ref_out,
+                         double* partials, double dt, void* stream) {
+    if (int rc = check_common(fn, p, nx, nz, ls)) return rc;
+    if (nf < 0 || nf > 64) return fail(CLOUDSC2_E_ARG, "%s: nf=%d outside [0, 64]", fn, nf);
+    if (nx == 0 || nf == 0) return CLOUDSC2_OK;
+    if (int rc = check_ptrs(fn, "in", in, NL_NUM_IN)) return rc;
+    if (int rc = check_ptrs(fn, "in_i", in_i, NL_NUM_IN)) return rc;
+    if (int rc = check_ptrs(fn, "ref_out", ref_out, NL_NUM_OUT)) return rc;
+    if (!eta) return fail(CLOUDSC2_E_ARG, "%s: eta is NULL", fn);
+    if (!pf) return fail(CLOUDSC2_E_ARG, "%s: pf is NULL", fn);
+    if (!partials) return fail(CLOUDSC2_E_ARG, "%s: partials is NULL", fn);
+    if (p->ICALL != 0) return fail(CLOUDSC2_E_UNSUPPORTED, "%s: ICALL=%d unsupported", fn, p->ICALL);
+    if (!(dt > 0.0)) return fail(CLOUDSC2_E_ARG, "%s: dt=%g must be > 0", fn, dt);
+    if (nz > 2000) return fail(CLOUDSC2_E_UNSUPPORTED, "%s: nz=%d: the level table and the running sums must share the LDS", fn, nz);
+    return launched(fn, cs2::launch_nl_taylor_multi<T>(*p, nx, nz, ls, in, in_i, nf, pf, eta, ref_out, partials, dt,
+                                                       static_cast<hipStream_t>(stream)));
+}
+
+template <typename T>
+int sums_impl(const char* fn, int32_t nx, int32_t nlev, int64_t ls, int32_t nf, const T* const* a, const T* const* b,
+              double* partials, void* stream) {
+    if (nx < 0 || nlev < 1 || ls < nx) return fail(CLOUDSC2_E_ARG, "%s: nx=%d nlev=%d lev_stride=%lld", fn, nx, nlev, (long long)ls);
+    if (nf < 1 || nf > 16) return fail(CLOUDSC2_E_ARG, "%s: nfields=%d outside [1, 16]", fn, nf);
+    if (nx == 0) return CLOUDSC2_OK;
+    if (int rc = check_ptrs(fn, "a", a, nf)) return rc;
+    if (b)
+        if (int rc = check_ptrs(fn, "b", b, nf)) return rc;
+    if (!partials) return fail(CLOUDSC2_E_ARG, "%s: partials is NULL", fn);
+    return launched(fn, cs2::launch_field_sums<T>(nx, nlev, ls, nf, a, b, partials, static_cast<hipStream_t>(stream)));
+}
+
+template <typename T>
+int dots_impl(const char* fn, int32_t nx, int32_t nlev, int64_t ls, int32_t np, const T* const* a, const T* const* b,
+              double* out, int32_t accumulate, void* stream) {
+    if (nx < 0 || nlev < 1 || ls < nx) return fail(CLOUDSC2_E_ARG, "%s: nx=%d nlev=%d lev_stride=%lld", fn, nx, nlev, (long long)ls);
+    if (np < 1 || np > 16) return fail(CLOUDSC2_E_ARG, "%s: npairs=%d outside [1, 16]", fn, np);
+    if (nx == 0) return CLOUDSC2_OK;
+    if (int rc = check_ptrs(fn, "a", a, np)) return rc;
+    if (int rc = check_ptrs(fn, "b", b, np)) return rc;
+    if (!out) return fail(CLOUDSC2_E_ARG, "%s: out is NULL", fn);
+    return launched(fn, cs2::launch_column_dots<T>(nx, nlev, ls, np, a, b, out, accumulate, static_cast<hipStream_t>(stream)));
 }
 
 template <typename T>
@@ -232,6 +287,35 @@ int32_t cloudsc2_nl_taylor_f32(const Cloudsc2Params* p, int32_t nx, int32_t nz, 
                                const float* const* in_i, double pf, const float* eta, const float* const* ref_out,
                                double* partials, double dt, void* stream) {
     return nl_taylor_impl<float>("cloudsc2_nl_taylor_f32", p, nx, nz, ls, in, in_i, pf, eta, ref_out, partials, dt, stream);
+}
+int32_t cloudsc2_nl_taylor_multi_f64(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls, const double* const* in,
+                                     const double* const* in_i, int32_t nf, const double* pf, const double* eta,
+                                     const double* const* ref_out, double* partials, double dt, void* stream) {
+    return nl_taylor_multi_impl<double>("cloudsc2_nl_taylor_multi_f64", p, nx, nz, ls, in, in_i, nf, pf, eta, ref_out,
+                                        partials, dt, stream);
+}
+int32_t cloudsc2_nl_taylor_multi_f32(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls, const float* const* in,
+                                     const float* const* in_i, int32_t nf, const double* pf, const float* eta,
+                                     const float* const* ref_out, double* partials, double dt, void* stream) {
+    return nl_taylor_multi_impl<float>("cloudsc2_nl_taylor_multi_f32", p, nx, nz, ls, in, in_i, nf, pf, eta, ref_out,
+                                       partials, dt, stream);
+}
+int32_t cloudsc2_field_sums_blocks(int32_t nx, int32_t nlev) { return cs2::field_sums_blocks(nx, nlev); }
+int32_t cloudsc2_field_sums_f64(int32_t nx, int32_t nlev, int64_t ls, int32_t nf, const double* const* a,
+                                const double* const* b, double* partials, void* stream) {
+    return sums_impl<double>("cloudsc2_field_sums_f64", nx, nlev, ls, nf, a, b, partials, stream);
+}
+int32_t cloudsc2_field_sums_f32(int32_t nx, int32_t nlev, int64_t ls, int32_t nf, const float* const* a,
+                                const float* const* b, double* partials, void* stream) {
+    return sums_impl<float>("cloudsc2_field_sums_f32", nx, nlev, ls, nf, a, b, partials, stream);
+}
+int32_t cloudsc2_column_dots_f64(int32_t nx, int32_t nlev, int64_t ls, int32_t np, const double* const* a,
+                                 const double* const* b, double* out, int32_t accumulate, void* stream) {
+    return dots_impl<double>("cloudsc2_column_dots_f64", nx, nlev, ls, np, a, b, out, accumulate, stream);
+}
+int32_t cloudsc2_column_dots_f32(int32_t nx, int32_t nlev, int64_t ls, int32_t np, const float* const* a,
+                                 const float* const* b, double* out, int32_t accumulate, void* stream) {
+    return dots_impl<float>("cloudsc2_column_dots_f32", nx, nlev, ls, np, a, b, out, accumulate, stream);
 }
 int32_t cloudsc2_tl_f64(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls, const double* const* in,
                         const double* const* in_i, const double* eta, double* const* out, double* const* out_i,

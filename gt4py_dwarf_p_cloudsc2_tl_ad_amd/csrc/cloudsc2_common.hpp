@@ -12,6 +12,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/cloudsc2_hip.h"
 
 namespace cs2 {
@@ -276,6 +278,38 @@ struct MPtrs { T* p[N]; };
 
 // diagnostics: the launchers record the name of the kernel they enqueued (cloudsc2_last_kernel(), thread-local)
 void note_kernel(const char* name);
+
+// ---- per-device facts the launchers cache (host side) ---------------------------------------------------------
+// The header asks for one host thread per device, but nothing here breaks if two threads launch on one device (a
+// capture thread beside the main thread): the caches are relaxed atomics, so a reader sees either "not yet known" and
+// repeats the (idempotent) query / hipFuncSetAttribute, or the final value - never a torn one.  Devices are indexed
+// directly; an ordinal beyond kMaxDevices is refused instead of aliased.
+constexpr int kMaxDevices = 64;
+inline int current_device(int& dev) {
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    return (dev >= 0 && dev < kMaxDevices) ? 0 : -2;
+}
+inline int device_cus(int dev) {
+    static std::atomic<int> cus[kMaxDevices] = {};
+    int n = cus[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+// > 64 KB of dynamic LDS needs an opt-in per kernel function: done once per instantiation (`done` is that
+// instantiation's own static array), device and size; sizes only grow.
+template <typename Kern>
+inline bool lds_opt_in(Kern kern, std::atomic<size_t>* done, int dev, size_t bytes) {
+    if (done[dev].load(std::memory_order_relaxed) >= bytes) return true;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            int(bytes)) != hipSuccess)
+        return false;
+    size_t cur = done[dev].load(std::memory_order_relaxed);
+    while (cur < bytes && !done[dev].compare_exchange_weak(cur, bytes, std::memory_order_relaxed)) {}
+    return true;
+}
 
 // Per-level LDS table: eta[k] and scalm[k] = ZSCAL * max(eta[k]-0.2, ZEPS1)^0.2
 // (nonlinear/_stencils/cloudsc2.py:127).  `pow` is evaluated once per level per workgroup instead

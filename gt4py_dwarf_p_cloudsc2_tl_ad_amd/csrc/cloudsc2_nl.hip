@@ -354,6 +354,15 @@ __device__ __forceinline__ void nl_store(const MPtrs<T, NL_NUM_OUT>& out, const 
     stg(out.p[NL_OUT_FHPSN], i + lsb, -o.sfln * e.RLSTT);
 }
 
+// Difference of an enthalpy flux against its stored reference, as the unfused sequence forms it: the flux is rounded to T
+// first (nl_store writes -flux * L), then the reference is subtracted - no fused multiply-subtract across the two.
+template <typename T>
+__device__ __forceinline__ T enthalpy_diff(T flux, T latent, T ref) {
+#pragma clang fp contract(off)
+    const T h = -flux * latent;
+    return h - ref;
+}
+
 #ifndef CS2_F32_WAVES
 #define CS2_F32_WAVES 1   // minimum waves per SIMD requested for the fp32 instantiations (register cap)
 #endif
@@ -489,8 +498,8 @@ nl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
                         acc[NL_OUT_TND_QI] += double(r.tnd_qi - ref[NL_OUT_TND_QI]);
                         acc[NL_OUT_FPLSL] += double(r.rfln - ref[NL_OUT_FPLSL]);
                         acc[NL_OUT_FPLSN] += double(r.sfln - ref[NL_OUT_FPLSN]);
-                        acc[NL_OUT_FHPSL] += double(-r.rfln * e.RLVTT - ref[NL_OUT_FHPSL]);
-                        acc[NL_OUT_FHPSN] += double(-r.sfln * e.RLSTT - ref[NL_OUT_FHPSN]);
+                        acc[NL_OUT_FHPSL] += double(enthalpy_diff<T>(r.rfln, e.RLVTT, ref[NL_OUT_FHPSL]));
+                        acc[NL_OUT_FHPSN] += double(enthalpy_diff<T>(r.sfln, e.RLSTT, ref[NL_OUT_FHPSN]));
                     }
                 } else {
                     if (live) nl_store<T>(out, e, lsb, o, r);
@@ -851,14 +860,8 @@ int launch_nl(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
     if (ring) {
         using G = RingGeom<T>;
         int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess) return -1;
-        static int cus[64] = {};
-        if (cus[dev & 63] == 0) {
-            int n = 0;
-            if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-            cus[dev & 63] = n;
-        }
-        const bool deep = int64_t(grid.x) * 2 <= int64_t(cus[dev & 63]) * 3;
+        if (const int rc = current_device(dev)) return rc;
+        const bool deep = int64_t(grid.x) * 2 <= int64_t(device_cus(dev)) * 3;
         ring_deep = deep;
         const int depth = deep ? CS2_NL_RING : 2;
         const size_t tab = (2 * size_t(nz + 1) * sizeof(T) + 1023) & ~size_t(1023);
@@ -868,7 +871,7 @@ int launch_nl(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
     if (ring) {
         using G = RingGeom<T>;
         int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess) return -1;
+        if (const int rc = current_device(dev)) return rc;
         const bool deep = ring_deep;
         const int depth = deep ? CS2_NL_RING : 2;
         const size_t tab = (2 * size_t(nz + 1) * sizeof(T) + 1023) & ~size_t(1023);
@@ -877,13 +880,8 @@ int launch_nl(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
     do {                                                                                                             \
         auto kern = nl_ring_kernel<T, EV, LN, sizeof(T) == 8, RD, SF>;                                               \
         /* > 64 KB of dynamic LDS needs the opt-in: once per instantiation, device and size */                       \
-        static size_t attr_set[64] = {};                                                                             \
-        if (attr_set[dev & 63] < rsmem) {                                                                            \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                    int(rsmem)) != hipSuccess)                                                       \
-                return -1;                                                                                           \
-            attr_set[dev & 63] = rsmem;                                                                              \
-        }                                                                                                            \
+        static std::atomic<size_t> attr_set[kMaxDevices] = {};                                                       \
+        if (!lds_opt_in(kern, attr_set, dev, rsmem)) return -1;                                                      \
         hipLaunchKernelGGL(kern, grid, block, rsmem, stream, e, kc, xk, nx, nz, ls, ci, eta, co, tdt, qsat_out,      \
                            keepq);                                                                                   \
     } while (0)
@@ -922,5 +920,258 @@ template int launch_nl<double>(const Cloudsc2Params&, int, int, int64_t, const d
                                double* const*, double, hipStream_t, const double* const*, double, double*, double*);
 template int launch_nl<float>(const Cloudsc2Params&, int, int, int64_t, const float* const*, const float*,
                               float* const*, double, hipStream_t, const float* const*, double, float*, double*);
+
+// ------------------------------------------------------------------------------------------------
+// The Taylor test's perturbed runs for NF step sizes in ONE launch (build extension, C ABI cloudsc2_nl_taylor_multi_*;
+// tangent_linear/validation.py:162-176 + :239-249 of the reference).  The perturbed NL run of one step size is bound by
+// its 42 words per level and column (16 state + 16 increment fields read, 10 outputs written or 10 reference outputs
+// read), ten times per Taylor run.  Here a lane loads the 42 words of a level ONCE and evaluates the level for NF step
+// sizes on them - NF independent carried states (rfl, sfl, covptot, aph_k) and tropopause profiles in registers - so the
+// ten perturbed runs cost 2 x 42 words instead of 10 x 42 and the kernel becomes bound by its arithmetic (NF x the NL
+// physics at one wave per SIMD), which also gives the VALU NF independent chains to interleave.  The 10 x NF running sums
+// sum_k (NL(x + f_j x_i) - NL(x)) live in LDS, [sum][lane] (conflict-free, no VGPRs), and are reduced per workgroup exactly
+// as the one-step variant (nl_kernel FUSE = 3) does: partials[(block * nf_total + f0 + j) * 10 + field], fixed order,
+// no atomics.  Same nl_level / nl_perturb / trpaus arithmetic as the one-step kernels on the same words.
+template <typename T, int NF>
+struct PFs { T f[NF]; };
+
+template <typename T, int NF>
+__device__ __forceinline__ void trpaus_prescan_multi(const T* __restrict__ pt, const T* __restrict__ ptt,
+                                                     const T* __restrict__ pt_i, const T* __restrict__ ptt_i, uint32_t lsb,
+                                                     uint32_t colb, T dt, const T* s_eta, int klo, int khi,
+                                                     const PFs<T, NF>& pf, T (&trpaus)[NF]) {
+#pragma unroll
+    for (int j = 0; j < NF; ++j) trpaus[j] = T(0.1);
+    if (klo > khi) return;
+    constexpr int CH = 8;
+    const uint32_t o0 = uint32_t(klo) * lsb + colb;
+    const T a0 = ldg(pt, o0), b0 = ldg(ptt, o0), ai0 = ldg(pt_i, o0), bi0 = ldg(ptt_i, o0);
+    T tk[NF];
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+        const T t0 = a0 + pf.f[j] * ai0;
+        const T tt0 = b0 + pf.f[j] * bi0;
+        tk[j] = t0 + dt * tt0;
+    }
+    for (int k0 = klo; k0 <= khi; k0 += CH) {
+        T a[CH], b[CH], ai[CH], bi[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int kk = (k0 + i < khi ? k0 + i : khi) + 1;   // the tail re-reads level khi + 1 (cache hits)
+            const uint32_t oi = uint32_t(kk) * lsb + colb;
+            a[i] = ldg(pt, oi);
+            b[i] = ldg(ptt, oi);
+            ai[i] = ldg(pt_i, oi);
+            bi[i] = ldg(ptt_i, oi);
+        }
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int k = k0 + i;
+            if (k <= khi) {
+                const T ek = s_eta[k];
+                const bool in_window = ek > T(0.1) && ek < T(0.4);
+#pragma unroll
+                for (int j = 0; j < NF; ++j) {
+                    const T aj = a[i] + pf.f[j] * ai[i];
+                    const T bj = b[i] + pf.f[j] * bi[i];
+                    const T tk1 = aj + dt * bj;
+                    if (in_window && tk[j] > tk1) trpaus[j] = ek;
+                    tk[j] = tk1;
+                }
+            }
+        }
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void nl_load_refs(const CPtrs<T, NL_NUM_OUT>& ref, uint32_t lsb, uint32_t o, T (&r)[NL_NUM_OUT]) {
+#pragma unroll
+    for (int f = 0; f < NL_NUM_OUT; ++f) {
+        const bool half = f == NL_OUT_FPLSL || f == NL_OUT_FPLSN || f == NL_OUT_FHPSL || f == NL_OUT_FHPSN;
+        r[f] = ldg(ref.p[f], half ? o + lsb : o);
+    }
+}
+
+template <typename T, bool EVAP, bool LIN, bool PINK, int NF>
+__global__ void __launch_bounds__(kColBlock, 1)
+nl_taylor_multi_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, NL_NUM_IN> in,
+                       CPtrs<T, NL_NUM_IN> in_i, CPtrs<T, NL_NUM_OUT> ref, const T* __restrict__ eta, T dt, PFs<T, NF> pf,
+                       double* __restrict__ partials, int nf_total, int f0) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    T* s_eta = reinterpret_cast<T*>(smem_raw);
+    T* s_scalm = s_eta + (nz + 1);
+    // running sums: [step size j][output field f][lane], after the level table (16-byte aligned)
+    double* const s_acc = reinterpret_cast<double*>(smem_raw + ((2u * uint32_t(nz + 1) * uint32_t(sizeof(T)) + 15u) & ~15u)) +
+                          threadIdx.x;
+    int klo, khi;
+    build_level_table<T>(eta, nz, e, s_eta, s_scalm, klo, khi);
+#pragma unroll
+    for (int i = 0; i < NF * NL_NUM_OUT; ++i) s_acc[i * kColBlock] = 0.0;   // this lane's own slots: no barrier needed
+    if constexpr (PINK && CS2_NL_PINK) {
+        pin_vgpr(e.RCPD); pin_vgpr(e.RLSTT); pin_vgpr(e.RLVTT); pin_vgpr(e.R4LES); pin_vgpr(e.R4IES);
+        pin_vgpr(e.RTT); pin_vgpr(e.RLPTRC); pin_vgpr(e.R3IES); pin_vgpr(e.R3LES); pin_vgpr(e.R2ES);
+        pin_vgpr(e.ZQMAX); pin_vgpr(e.RETV); pin_vgpr(e.R5LES); pin_vgpr(e.R5IES); pin_vgpr(e.RTICE);
+        pin_vgpr(e.RG); pin_vgpr(e.RD); pin_vgpr(e.R5ALVCP); pin_vgpr(e.RALVDCP); pin_vgpr(e.R5ALSCP);
+        pin_vgpr(e.RALSDCP); pin_vgpr(kc.rdt); pin_vgpr(kc.cons2); pin_vgpr(kc.rRD); pin_vgpr(kc.rRCPD);
+        pin_vgpr(kc.cormax); pin_vgpr(kc.fw2); pin_vgpr(dt);
+    }
+    if constexpr (PINK && CS2_NL_PINX && CS2_NL_FEXP) {
+        pin_vgpr(xk.l2e); pin_vgpr(xk.ln2h); pin_vgpr(xk.ln2l); pin_vgpr(xk.c12); pin_vgpr(xk.c11);
+        pin_vgpr(xk.c10); pin_vgpr(xk.c9); pin_vgpr(xk.c8); pin_vgpr(xk.c7); pin_vgpr(xk.c6);
+        pin_vgpr(xk.c5); pin_vgpr(xk.c4); pin_vgpr(xk.c3);
+    }
+    const int gcol = xcd_block() * kColBlock + threadIdx.x;
+    const bool live = gcol < nx;
+    const int col = live ? gcol : nx - 1;   // dead lanes shadow the last column and add nothing
+    const uint32_t lsb = uint32_t(ls) * uint32_t(sizeof(T));
+    const uint32_t colb = uint32_t(col) * uint32_t(sizeof(T));
+
+    T trpaus[NF];
+    trpaus_prescan_multi<T, NF>(in.p[NL_IN_T], in.p[NL_IN_TND_CML_T], in_i.p[NL_IN_T], in_i.p[NL_IN_TND_CML_T], lsb, colb, dt,
+                                s_eta, klo, khi, pf, trpaus);
+    CrhCol<T> crh[NF];
+    NLCarry<T> c[NF];
+    T aph_s[NF];
+    {
+        const T aph0 = ldg(in.p[NL_IN_APH], colb), aph0_i = ldg(in_i.p[NL_IN_APH], colb);
+        T aphs = T(1.0), aphs_i = T(0.0);
+        if constexpr (EVAP) {
+            aphs = ldg(in.p[NL_IN_APH], uint32_t(nz) * lsb + colb);
+            aphs_i = ldg(in_i.p[NL_IN_APH], uint32_t(nz) * lsb + colb);
+        }
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            crh[j] = crh_setup<T>(trpaus[j]);
+            c[j].rfl = T(0.0);
+            c[j].sfl = T(0.0);
+            c[j].covptot = T(0.0);
+            c[j].aph_k = aph0 + pf.f[j] * aph0_i;
+            aph_s[j] = EVAP ? aphs + pf.f[j] * aphs_i : T(1.0);
+        }
+    }
+
+    // register double buffer: level k+1's 42 words are requested before level k's NF evaluations
+    NLIn<T> bufa[2], bufb[2];
+    T bufr[2][NL_NUM_OUT];
+    bufa[0] = nl_load<T, false>(in, lsb, colb);
+    bufb[0] = nl_load<T, false>(in_i, lsb, colb);
+    nl_load_refs<T>(ref, lsb, colb, bufr[0]);
+    bufa[1] = bufa[0];
+    bufb[1] = bufb[0];
+#pragma unroll
+    for (int f = 0; f < NL_NUM_OUT; ++f) bufr[1][f] = bufr[0][f];
+    uint32_t o = colb;
+    for (int k0 = 0; k0 < nz; k0 += 2) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int k = k0 + s;
+            if (k < nz) {
+                if (k + 1 < nz) {
+                    bufa[s ^ 1] = nl_load<T, false>(in, lsb, o + lsb);
+                    bufb[s ^ 1] = nl_load<T, false>(in_i, lsb, o + lsb);
+                    nl_load_refs<T>(ref, lsb, o + lsb, bufr[s ^ 1]);
+                }
+                const T eta_k = s_eta[k], scalm_k = s_scalm[k];
+#pragma unroll
+                for (int j = 0; j < NF; ++j) {
+                    const NLIn<T> x = nl_perturb<T>(bufa[s], bufb[s], pf.f[j]);
+                    const NLOut<T> r = nl_level<T, EVAP, LIN>(e, kc, xk, x, eta_k, scalm_k, crh[j], dt, aph_s[j], c[j]);
+                    if (live) {
+                        double* const a = s_acc + j * NL_NUM_OUT * kColBlock;
+                        a[NL_OUT_CLC * kColBlock] += double(r.clc - bufr[s][NL_OUT_CLC]);
+                        a[NL_OUT_COVPTOT * kColBlock] += double(r.covptot - bufr[s][NL_OUT_COVPTOT]);
+                        a[NL_OUT_TND_Q * kColBlock] += double(r.tnd_q - bufr[s][NL_OUT_TND_Q]);
+                        a[NL_OUT_TND_T * kColBlock] += double(r.tnd_t - bufr[s][NL_OUT_TND_T]);
+                        a[NL_OUT_TND_QL * kColBlock] += double(r.tnd_ql - bufr[s][NL_OUT_TND_QL]);
+                        a[NL_OUT_TND_QI * kColBlock] += double(r.tnd_qi - bufr[s][NL_OUT_TND_QI]);
+                        a[NL_OUT_FPLSL * kColBlock] += double(r.rfln - bufr[s][NL_OUT_FPLSL]);
+                        a[NL_OUT_FPLSN * kColBlock] += double(r.sfln - bufr[s][NL_OUT_FPLSN]);
+                        a[NL_OUT_FHPSL * kColBlock] += double(enthalpy_diff<T>(r.rfln, e.RLVTT, bufr[s][NL_OUT_FHPSL]));
+                        a[NL_OUT_FHPSN * kColBlock] += double(enthalpy_diff<T>(r.sfln, e.RLSTT, bufr[s][NL_OUT_FHPSN]));
+                    }
+                }
+                o += lsb;
+            }
+        }
+    }
+    // workgroup reduction of the NF x 10 sums: wave shuffle, then one LDS hop
+    __shared__ double s_red[kColBlock / 64][NF * NL_NUM_OUT];
+#pragma unroll
+    for (int i = 0; i < NF * NL_NUM_OUT; ++i) {
+        double v = s_acc[i * kColBlock];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NF * NL_NUM_OUT) {
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < kColBlock / 64; ++w) v += s_red[w][threadIdx.x];
+        const int j = threadIdx.x / NL_NUM_OUT, f = threadIdx.x % NL_NUM_OUT;
+        partials[(size_t(blockIdx.x) * size_t(nf_total) + size_t(f0 + j)) * NL_NUM_OUT + f] = v;
+    }
+}
+
+#ifndef CS2_NL_MULTI_NF
+#define CS2_NL_MULTI_NF 5   // step sizes per launch: 10 x NF fp64 running sums x 256 lanes must fit the CU's LDS
+#endif
+template <typename T>
+int launch_nl_taylor_multi(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* const* in, const T* const* in_i,
+                           int nf, const double* pfs, const T* eta, const T* const* ref_out, double* partials, double dt,
+                           hipStream_t stream) {
+    const Ext<T> e = make_ext<T>(p);
+    CPtrs<T, NL_NUM_IN> ci, cii;
+    CPtrs<T, NL_NUM_OUT> cr;
+    for (int i = 0; i < NL_NUM_IN; ++i) { ci.p[i] = in[i]; cii.p[i] = in_i[i]; }
+    for (int i = 0; i < NL_NUM_OUT; ++i) cr.p[i] = ref_out[i];
+    const dim3 grid((nx + kColBlock - 1) / kColBlock), block(kColBlock);
+    const bool evap = p.LEVAPLS2 || p.LDRAIN1D;
+    const bool lin = p.LPHYLIN || p.LDRAIN1D;
+    const T tdt = static_cast<T>(dt);
+    const NLK<T> kc = make_nlk<T>(p, dt, evap);
+    const ExpK<T> xk = make_expk<T>();
+    if (!fits_u32_offsets<T>(nz, ls)) return -2;
+    int dev = 0;
+    if (const int rc = current_device(dev)) return rc;
+    const size_t tab = (2 * size_t(nz + 1) * sizeof(T) + 15) & ~size_t(15);
+#define CS2_NLM_LAUNCH(EV, LN, NFV)                                                                                    \
+    do {                                                                                                                \
+        auto kern = nl_taylor_multi_kernel<T, EV, LN, sizeof(T) == 8, NFV>;                                             \
+        const size_t smem = tab + size_t(NFV) * NL_NUM_OUT * kColBlock * sizeof(double);                                \
+        if (smem + sizeof(double) * (kColBlock / 64) * NFV * NL_NUM_OUT > size_t(160) * 1024) return -2;                \
+        static std::atomic<size_t> attr_set[kMaxDevices] = {};                                                          \
+        if (smem > size_t(64) * 1024 && !lds_opt_in(kern, attr_set, dev, smem)) return -1;                              \
+        PFs<T, NFV> pf;                                                                                                 \
+        for (int j = 0; j < NFV; ++j) pf.f[j] = static_cast<T>(pfs[f0 + j]);                                            \
+        hipLaunchKernelGGL(kern, grid, block, smem, stream, e, kc, xk, nx, nz, ls, ci, cii, cr, eta, tdt, pf, partials, \
+                           nf, f0);                                                                                     \
+    } while (0)
+#define CS2_NLM_FLAGS(NFV)                                            \
+    do {                                                              \
+        if (evap && lin) CS2_NLM_LAUNCH(true, true, NFV);             \
+        else if (evap && !lin) CS2_NLM_LAUNCH(true, false, NFV);      \
+        else if (!evap && lin) CS2_NLM_LAUNCH(false, true, NFV);      \
+        else CS2_NLM_LAUNCH(false, false, NFV);                       \
+    } while (0)
+    for (int f0 = 0; f0 < nf;) {
+        const int left = nf - f0;
+        if (left >= CS2_NL_MULTI_NF) { CS2_NLM_FLAGS(CS2_NL_MULTI_NF); f0 += CS2_NL_MULTI_NF; }
+        else if (left >= 3 && CS2_NL_MULTI_NF > 3) { CS2_NLM_FLAGS(3); f0 += 3; }
+        else if (left == 2) { CS2_NLM_FLAGS(2); f0 += 2; }
+        else { CS2_NLM_FLAGS(1); f0 += 1; }
+    }
+#undef CS2_NLM_FLAGS
+#undef CS2_NLM_LAUNCH
+    note_kernel("cs2::nl_taylor_multi_kernel");
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+template int launch_nl_taylor_multi<double>(const Cloudsc2Params&, int, int, int64_t, const double* const*,
+                                            const double* const*, int, const double*, const double*, const double* const*,
+                                            double*, double, hipStream_t);
+template int launch_nl_taylor_multi<float>(const Cloudsc2Params&, int, int, int64_t, const float* const*,
+                                           const float* const*, int, const double*, const float*, const float* const*,
+                                           double*, double, hipStream_t);
 
 }  // namespace cs2

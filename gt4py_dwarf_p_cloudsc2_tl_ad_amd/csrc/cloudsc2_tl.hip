@@ -624,7 +624,7 @@ tl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
 //     its DMAs are the (RD-1) x NI DMAs of the levels in flight and the (RD-1) x 20 stores of the levels computed since.
 //     Unlike nl_ring_kernel (three slots, one level of stores of slack) the count is EXACT here: with two slots a
 //     stricter wait would expose the completion latency of the previous level's stores on every level.  tl_store
-//     issues exactly kTLStores stores per level (20 distinct fields; profiles/check_ring_counts.py counts them in the ISA).
+//     issues exactly kTLStores stores per level (20 distinct fields; tests/test_ring_isa.py counts them in the compiled ISA, and __graft_entry__.build() runs that check whenever it recompiles).
 // Used when the launcher can guarantee 16-byte aligned rows and whole waves (launch_tl); every other call takes the
 // register-prefetch kernel above.  Results are bit-identical (same arithmetic on the same words).
 #ifndef CS2_TL_RING
@@ -860,7 +860,8 @@ int launch_tl(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
         const size_t rsmem = tab + size_t(kColBlock / 64) * kRing * G::SLOT;
         ring = ring && rsmem <= size_t(160) * 1024;   // LDS of a CU; very tall columns take the register path
         int dev = 0;
-        if (ring && hipGetDevice(&dev) != hipSuccess) return -1;
+        if (ring)
+            if (const int rc = current_device(dev)) return rc;
 #ifndef CS2_TL_RING_ALWAYS
 #define CS2_TL_RING_ALWAYS 0   // A/B switch: 1 = take the ring whenever it is legal, whatever the occupancy
 #endif
@@ -871,13 +872,7 @@ int launch_tl(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
             // (65 536: 720 vs 710 us, 131 072: 1 518 vs 1 488 us; profiles/r02/ab_tl_ring.txt).  Rule: register path when
             // at least 3/4 of the launch's workgroup rounds are full.  fp32 (8 KB slots): the ring wins at every size
             // measured (65 536: 337 vs 389 us; 524 288: 2 986 vs 3 049 us).
-            static int cus[64] = {};
-            if (cus[dev & 63] == 0) {
-                int n = 0;
-                if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-                cus[dev & 63] = n;
-            }
-            const int64_t c = cus[dev & 63], gx = grid.x;
+            const int64_t c = device_cus(dev), gx = grid.x;
             const int64_t full = gx / c, rounds = (gx + c - 1) / c;
             ring = 4 * full < 3 * rounds;
         }
@@ -886,13 +881,8 @@ int launch_tl(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
     do {                                                                                                             \
         auto kern = tl_ring_kernel<T, REG, EVAP, kRing>;                                                             \
         /* > 64 KB of dynamic LDS needs the opt-in: once per instantiation, device and size */                       \
-        static size_t attr_set[64] = {};                                                                             \
-        if (attr_set[dev & 63] < rsmem) {                                                                            \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                    int(rsmem)) != hipSuccess)                                                       \
-                return -1;                                                                                           \
-            attr_set[dev & 63] = rsmem;                                                                              \
-        }                                                                                                            \
+        static std::atomic<size_t> attr_set[kMaxDevices] = {};                                                       \
+        if (!lds_opt_in(kern, attr_set, dev, rsmem)) return -1;                                                      \
         hipLaunchKernelGGL(kern, grid, block, rsmem, stream, e, kc, xk, nx, nz, ls, ci, cii, eta, co, coi, tdt);     \
     } while (0)
             if (p.LREGCL) {

@@ -175,18 +175,21 @@ def init_distributed_from_env() -> None:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
 
-def tune_field_placement(field_dicts, objective, **tuner_kw) -> Dict[str, Any]:
+def tune_field_placement(field_dicts, objective, *, _any_device: bool = False, **tuner_kw) -> Dict[str, Any]:
     """Re-place every 3-D GPU field found in `field_dicts` (dicts name -> DataArray; a field shared by several dicts or
     DataArrays is one field) at the placement `storage.tune_placement` measures to be fastest for `objective()` - the
     caller's own timed region, run on the candidate placement.  Contents are preserved; the DataArrays are re-pointed at
-    the new storages in place, so every dict keeps working.  Returns the tuner's report."""
+    the new storages in place, so every dict keeps working.  Returns the tuner's report.
+    Exception-safe: if the tuner or the objective raises (out of memory, no room for the arena, a failing stencil), every
+    DataArray is pointed back at its original storage with its original contents and the report carries `error` - the
+    caller goes on untuned, as bench.py does.  (`_any_device`: lets the CPU unit test drive this with host tensors.)"""
     from ..framework.fields import FieldTensor
 
     by_ptr: Dict[int, list] = {}
     for d in field_dicts:
         for v in d.values():
             t = getattr(v, "data", None)
-            if isinstance(v, DataArray) and isinstance(t, torch.Tensor) and t.dim() == 3 and t.is_cuda and t.shape[1] == 1:
+            if isinstance(v, DataArray) and isinstance(t, torch.Tensor) and t.dim() == 3 and (t.is_cuda or _any_device) and t.shape[1] == 1:
                 by_ptr.setdefault(t.data_ptr(), [])
                 if all(v is not w for w in by_ptr[t.data_ptr()]):
                     by_ptr[t.data_ptr()].append(v)
@@ -200,23 +203,41 @@ def tune_field_placement(field_dicts, objective, **tuner_kw) -> Dict[str, Any]:
     order = [f"f{i}" for i in range(len(groups))]
     sources = {n: storage.klayout(g[0].data.as_subclass(torch.Tensor)).clone() for n, g in zip(order, groups)}
 
-    def launch(fields):
+    originals = [[da.data for da in g] for g in groups]     # kept until the tuner has returned: a failure restores them
+
+    def point_at(fields):
         for n, g in zip(order, groups):
             for da in g:
                 da.data = fields[n].as_subclass(FieldTensor)
+
+    def launch(fields):
+        point_at(fields)
         objective()
 
     np_dtype = {torch.float64: np.float64, torch.float32: np.float32}[first.dtype]
-    fields, report = storage.tune_placement(nx, nz, np_dtype, first.device, order, sources, launch, **tuner_kw)
-    for n, g in zip(order, groups):
-        for da in g:
-            da.data = fields[n].as_subclass(FieldTensor)
+    try:
+        fields, report = storage.tune_placement(nx, nz, np_dtype, first.device, order, sources, launch, **tuner_kw)
+    except Exception as exc:  # noqa: BLE001 - e.g. out of memory, "do not fit 60 % of the free device memory", a failing objective
+        # the state must not be left pointing into a half-tuned arena with its inout fields modified by candidate runs:
+        # every DataArray goes back to its original storage with its original contents, and the caller runs untuned
+        for g, olds, n in zip(groups, originals, order):
+            storage.klayout(olds[0].as_subclass(torch.Tensor)).copy_(sources[n])
+            for da, old in zip(g, olds):
+                da.data = old
+        if first.is_cuda:
+            torch.cuda.empty_cache()
+        return {"fields": len(groups), "error": f"{type(exc).__name__}: {exc}"[:300]}
+    point_at(fields)
     report["fields"] = len(groups)
     return report
 
 
 def report_placement(rep: Dict[str, Any], unit: str = "run") -> None:
     """the line the drivers print after `--tune-placement`"""
+    if rep.get("error"):
+        print(f"[cloudsc2-hip] field placement NOT tuned ({rep['error']}): the {rep.get('fields')} fields stay where they "
+              "were, the run continues on the untuned placement")
+        return
     print(f"[cloudsc2-hip] field placement tuned over {rep.get('candidates')} candidates: "
           f"{rep.get('default_ms', 0):.4f} -> {rep.get('tuned_ms', 0):.4f} ms per {unit} "
           f"(+{rep.get('extra_spacing_x2MB')} x 2 MB slab spacing, stagger {rep.get('stagger_bytes')} B, "

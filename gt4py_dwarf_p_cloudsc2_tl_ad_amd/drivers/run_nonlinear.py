@@ -38,8 +38,10 @@ def core(args):
         # this process, with the timed region itself as the objective; contents and results are unchanged
         saved = cfg.gt4py_config.exec_info
         cfg.gt4py_config.exec_info = None
-        rep = tune_field_placement([state, diags, tends], one_run)
-        cfg.gt4py_config.exec_info = saved
+        try:
+            rep = tune_field_placement([state, diags, tends], one_run)
+        finally:
+            cfg.gt4py_config.exec_info = saved
         ctx["placement"] = rep
         report_placement(rep, "run")
     graph = None

@@ -16,7 +16,7 @@ def core(args):
                     lphylin=True, ldrain1d=False, yoethf_params=p["yoethf"], yomcst_params=p["yomcst"],
                     yrecldp_params=p["yrecldp"], yrephli_params=p["yrephli"], yrncl_params=p["yrncl"],
                     yrphnc_params=p["yrphnc"], enable_checks=cfg.sympl_enable_checks, gt4py_config=cfg.gt4py_config,
-                    fused=args.fused, fused_norms=args.fused_norms)
+                    fused=args.fused, fused_norms=args.fused_norms, fused_all=args.fused_all, graph=args.graph)
     norms = tt.run(ctx["state"], ctx["dt"])                  # warm-up; these norms are the validated ones
     if args.tune_placement:
         # build extension: the ~90 fields of the test are re-placed in HBM where a whole run is fastest
@@ -33,7 +33,7 @@ def core(args):
     mean = statistics.fmean(runtimes)
     std = statistics.stdev(runtimes) if len(runtimes) > 1 else 0.0
     print(f"\nThe test completed in {mean:.3f} ± {std:.3f} ms.")
-    ctx.update(norms=norms, passed=ok, runtimes_ms=runtimes)
+    ctx.update(norms=norms, passed=ok, runtimes_ms=runtimes, harness=tt)
     return ctx
 
 
@@ -44,6 +44,11 @@ def main(argv=None):
                     help="apply the perturbation inside the NL kernel (build extension cloudsc2_nl_perturbed)")
     ap.add_argument("--fused-norms", action="store_true",
                     help="--fused + the ten difference sums formed in the kernel epilogue (cloudsc2_nl_taylor)")
+    ap.add_argument("--fused-all", action="store_true",
+                    help="all ten perturbed runs in two launches that share the loads of a level and form the sums in "
+                         "their epilogue (build extension cloudsc2_nl_taylor_multi)")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture a run's kernel sequence in a HIP graph and replay it (one host call per run)")
     ap.add_argument("--tune-placement", action="store_true",
                     help="measure and fix the HBM placement of the test's fields for this process (storage.tune_placement)")
     args = ap.parse_args(argv)

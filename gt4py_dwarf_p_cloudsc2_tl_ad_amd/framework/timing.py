@@ -10,7 +10,9 @@ import torch
 
 
 def _sync() -> None:
-    if torch.cuda.is_available():
+    # while a HIP graph is being captured (harness / driver `--graph` modes) nothing may synchronise: the timers then
+    # measure nothing, and the replay is timed by the caller
+    if torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
         torch.cuda.synchronize()
 
 

@@ -34,7 +34,7 @@ _INT_FIELDS = (
     "AD_TRAJ_FIX",  # build extension (not a reference external), see include/cloudsc2_hip.h
 )
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class Cloudsc2Params(ctypes.Structure):

@@ -110,6 +110,12 @@ class HipStencil:
         if nx == 0:
             return
         ptrs = {n: f.data_ptr() for n, f in fields.items()}
+        # the O(n^2) window test (26 outputs x 72 fields for cloudsc2_ad: ~1 ms of host Python) runs once per distinct set
+        # of storages; the drivers call a stencil on the same storages run after run
+        key = (tuple(ptrs.items()), nx, nlev, ls, itemsize)
+        seen = self.__dict__.setdefault("_disjoint_ok", set())
+        if key in seen:
+            return
         outs = [n for n in fields if n.startswith("out_")]
         for o in outs:
             for n, p in ptrs.items():
@@ -118,6 +124,9 @@ class HipStencil:
                 if _windows_overlap(ptrs[o], p, itemsize, nx, nlev, ls):
                     raise ValueError(f"{self.name}: output '{o}' overlaps '{n}' in memory - inputs and outputs of "
                                      "one call must be disjoint storages")
+        if len(seen) >= 64:
+            seen.clear()
+        seen.add(key)
 
     def _collect(self, kwargs: Dict[str, Any]) -> Dict[str, torch.Tensor]:
         fields = {}
@@ -284,6 +293,40 @@ class Cloudsc2NLTaylorStencil(HipStencil):
             _ptrs(fields, ["ref_" + n for n in NL_OUT]), part.data_ptr(), scalar, stream)
 
 
+class Cloudsc2NLTaylorMultiStencil(HipStencil):
+    """BUILD EXTENSION `cloudsc2_nl_taylor_multi`: the Taylor test's perturbed NL runs for ALL step sizes (C ABI
+    `cloudsc2_nl_taylor_multi_*`: up to 5 step sizes share one pass over the 42 words of a level).  Fields as
+    `cloudsc2_nl_taylor`; `fs`: the step sizes; `out_partials`: contiguous float64 tensor of shape
+    (taylor_blocks(nx), len(fs), 10) receiving, per workgroup and step size, sum(NL(in + f in_i) - ref) in NL_OUT order."""
+
+    name = "cloudsc2_nl_taylor_multi"
+
+    def __call__(self, **kwargs: Any) -> None:
+        if "fs" not in kwargs or "out_partials" not in kwargs:
+            raise TypeError(f"{self.name}: missing argument 'fs' / 'out_partials'")
+        self._fs = [float(x) for x in kwargs.pop("fs")]
+        self._partials = kwargs.pop("out_partials")
+        super().__call__(**kwargs)
+
+    def _field_names(self):
+        return (tuple("in_" + n for n in NL_IN) + tuple("in_" + n + "_i" for n in NL_IN)
+                + tuple("ref_" + n for n in NL_OUT))
+
+    def _launch(self, fields, eta, scalar, nx, nz, ls, sfx, stream):
+        if eta is None:
+            raise TypeError(f"{self.name}: missing field argument 'in_eta'")
+        part, nf = self._partials, len(self._fs)
+        need = taylor_blocks(nx) * nf * len(NL_OUT)
+        if (not isinstance(part, torch.Tensor) or part.dtype != torch.float64 or not part.is_contiguous()
+                or part.device != fields["in_ap"].device or part.numel() < need):
+            raise ValueError(f"{self.name}: out_partials must be a contiguous float64 device tensor with >= {need} elements")
+        pf = (ctypes.c_double * max(nf, 1))(*self._fs)
+        return self._fn("nl_taylor_multi", sfx)(
+            ctypes.byref(self.params), nx, nz, ls, _ptrs(fields, ["in_" + n for n in NL_IN]),
+            _ptrs(fields, ["in_" + n + "_i" for n in NL_IN]), nf, pf, eta.data_ptr(),
+            _ptrs(fields, ["ref_" + n for n in NL_OUT]), part.data_ptr(), scalar, stream)
+
+
 def taylor_blocks(nx: int) -> int:
     """Number of per-workgroup partial rows `cloudsc2_nl_taylor` writes for nx columns."""
     return int(_lib.load().cloudsc2_nl_taylor_blocks(int(nx)))
@@ -386,6 +429,7 @@ STENCILS: Dict[str, type] = {
     "cloudsc2_nl_saturation": Cloudsc2NLSaturationStencil,   # build extension (fused)
     "cloudsc2_nl_perturbed": Cloudsc2NLPerturbedStencil,     # build extension (fused)
     "cloudsc2_nl_taylor": Cloudsc2NLTaylorStencil,           # build extension (fused + reduction)
+    "cloudsc2_nl_taylor_multi": Cloudsc2NLTaylorMultiStencil,   # build extension (all step sizes, fused + reduction)
     "cloudsc2_tl": Cloudsc2TLStencil,
     "cloudsc2_ad": Cloudsc2ADStencil,
     "saturation": SaturationStencil,

@@ -98,6 +98,31 @@ class FieldArena:
         return logical_view(self._buf[o:o + n].view(self.nz + 1, self.nx))
 
 
+def plan_placement_grid(n: int, slab: int, free_bytes: Optional[int], *, spacings, staggers, shifts_mb, wide_spacings,
+                        wide_shifts_mb, max_arena_bytes: int, max_shift_spans: float):
+    """The candidate placements `tune_placement` will time for `n` fields of `slab` bytes, and the size of the ONE arena
+    that holds them all: never more than `max_arena_bytes` and never more than 60 % of `free_bytes` (what the device
+    has free NOW - on a node with one process per GPU that is the caller's own device, so eight ranks plan eight
+    independent arenas).  Returns (grid of (extra spacing x 2 MB, stagger, shift bytes), arena bytes, spacings kept);
+    raises RuntimeError when not even the densest placement fits."""
+    two_mb = FieldArena.SLAB_ALIGN
+    free_cap = int(0.6 * free_bytes) if free_bytes is not None else max_arena_bytes
+    max_arena_bytes = min(max_arena_bytes, free_cap)        # never ask for more than 60 % of what is free now
+    fit = [e for e in spacings if n * (slab + e * two_mb) + two_mb <= max_arena_bytes]
+    if not fit:
+        raise RuntimeError(f"tune_placement: {n} fields of {slab} B do not fit 60 % of the free device memory")
+    spacings = tuple(fit)
+    emax = max(spacings)
+    span = n * (slab + emax * two_mb) + two_mb
+    shifts = [int(sh) << 20 for sh in shifts_mb
+              if span + (int(sh) << 20) <= max_arena_bytes and (int(sh) << 20) <= max_shift_spans * span] or [0]
+    grid = [(e, st, sh) for sh in shifts for e in spacings for st in staggers]
+    grid += [(e, st, int(sh) << 20) for e in wide_spacings for sh in wide_shifts_mb for st in staggers
+             if n * (slab + e * two_mb) + two_mb + (int(sh) << 20) <= max_arena_bytes]
+    arena_need = max(n * (slab + e * two_mb) + two_mb + sh for e, _, sh in grid)
+    return grid, arena_need, spacings
+
+
 def tune_placement(nx: int, nz: int, dtype: Any, device: Any, order, sources, launch, *, spacings=tuple(range(0, 64)),
                    staggers=(FieldArena.STAGGER, 8448), shifts_mb=(0, 4096, 8192, 12288), wide_spacings=(),
                    wide_shifts_mb=tuple(range(0, 32769, 2048)), launches: int = 5, rounds: int = 3,
@@ -132,24 +157,11 @@ def tune_placement(nx: int, nz: int, dtype: Any, device: Any, order, sources, la
     n = len(order)
     two_mb = FieldArena.SLAB_ALIGN
     slab = -(-((nz + 1) * nx * item + FieldArena.STAGGER_WRAP) // two_mb) * two_mb
-    free_cap = int(0.6 * torch.cuda.mem_get_info(dev)[0]) if dev.type == "cuda" else max_arena_bytes
-    max_arena_bytes = min(max_arena_bytes, free_cap)        # never ask for more than 60 % of what is free now
-    fit = [e for e in spacings if n * (slab + e * two_mb) + two_mb <= max_arena_bytes]
-    if not fit:
-        raise RuntimeError(f"tune_placement: {n} fields of {slab} B do not fit 60 % of the free device memory")
-    spacings = tuple(fit)
-    emax = max(spacings)
-    span = n * (slab + emax * two_mb) + two_mb
-    if os.environ.get("CLOUDSC2_TUNE_SHIFTS_MB"):      # dev switch for A/B runs of the grid (profiles/tuner_ab.sh)
-        shifts_mb = tuple(int(x) for x in os.environ["CLOUDSC2_TUNE_SHIFTS_MB"].split(","))
-        max_arena_bytes = max(max_arena_bytes, min(free_cap, 96 << 30))
-        max_shift_spans = 1e9
-    shifts = [int(sh) << 20 for sh in shifts_mb
-              if span + (int(sh) << 20) <= max_arena_bytes and (int(sh) << 20) <= max_shift_spans * span] or [0]
-    grid = [(e, st, sh) for sh in shifts for e in spacings for st in staggers]
-    grid += [(e, st, int(sh) << 20) for e in wide_spacings for sh in wide_shifts_mb for st in staggers
-             if n * (slab + e * two_mb) + two_mb + (int(sh) << 20) <= max_arena_bytes]
-    arena_need = max(n * (slab + e * two_mb) + two_mb + sh for e, _, sh in grid)
+    # what is free on THIS device now (one process per GPU: every rank sizes its arena against its own device)
+    free_bytes = torch.cuda.mem_get_info(dev)[0] if dev.type == "cuda" else None
+    grid, arena_need, spacings = plan_placement_grid(
+        n, slab, free_bytes, spacings=spacings, staggers=staggers, shifts_mb=shifts_mb, wide_spacings=wide_spacings,
+        wide_shifts_mb=wide_shifts_mb, max_arena_bytes=max_arena_bytes, max_shift_spans=max_shift_spans)
     buf = torch.zeros(arena_need // item, dtype=dt, device=dev)
     base = (-buf.data_ptr()) % two_mb
     count = (nz + 1) * nx

@@ -24,9 +24,10 @@
  *   - return value: 0 on success, <0 on error (CLOUDSC2_E_*); `cloudsc2_last_error()` returns a
  *     thread-local message.  Kernels are launched asynchronously on `stream`;
  *   - threading: the library is written for ONE host thread per process and device (the one-process-per-GPU
- *     model of the drivers).  Error text and kernel-name diagnostics are thread-local, but the launchers cache
- *     per-device facts (CU count, the >64 KiB LDS opt-in of the ring kernels) in unsynchronised statics: calling
- *     entry points of the same device concurrently from several threads needs external serialisation;
+ *     model of the drivers).  Error text and kernel-name diagnostics are thread-local; the per-device facts the
+ *     launchers cache (CU count, the >64 KiB LDS opt-in of the ring kernels) are relaxed atomics whose only race
+ *     is a repeated, idempotent query, so a second thread launching on the same device is safe.  Device ordinals
+ *     >= 64 are refused (CLOUDSC2_E_UNSUPPORTED);
  *   - inputs and outputs of one call must not overlap (no in-place calls): the kernels stream level by level
  *     and cloudsc2_ad re-reads its inputs in its second sweep.  The Python stencil objects check this when
  *     called with validate_args=True.
@@ -40,7 +41,7 @@
 extern "C" {
 #endif
 
-#define CLOUDSC2_ABI_VERSION 2
+#define CLOUDSC2_ABI_VERSION 3
 
 #define CLOUDSC2_OK 0
 #define CLOUDSC2_E_ARG (-1)      /* bad argument (null pointer, nx/nz/stride out of range)      */
@@ -122,6 +123,39 @@ int32_t cloudsc2_nl_taylor_f64(const Cloudsc2Params* p, int32_t nx, int32_t nz, 
 int32_t cloudsc2_nl_taylor_f32(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t lev_stride,
                                const float* const* in, const float* const* in_i, double pf, const float* eta,
                                const float* const* ref_out, double* partials, double dt, void* stream);
+
+/* ---- the Taylor test's perturbed runs for SEVERAL step sizes per launch (BUILD EXTENSION).
+ * Replaces the whole loop of TaylorTest.run (tangent_linear/validation.py:162-176: perturbed_state, cloudsc2_nl, get_norm
+ * per step size): a lane loads the 16 state + 16 increment + 10 reference words of a level once and evaluates the level
+ * for up to 5 step sizes on them (internally ceil(nf / 5) launches), so the perturbed runs are bound by arithmetic instead
+ * of re-streaming 42 words per level, column and step size.  `pf`: HOST array of the nf step sizes; `partials`: DEVICE
+ * array of cloudsc2_nl_taylor_blocks(nx) * nf * NL_NUM_OUT doubles, partials[(b * nf + j) * NL_NUM_OUT + f] = sum over
+ * workgroup b's columns and all levels of (NL(in + pf[j] in_i) - ref_out)[f]; the caller adds the blocks. */
+int32_t cloudsc2_nl_taylor_multi_f64(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t lev_stride,
+                                     const double* const* in, const double* const* in_i, int32_t nf, const double* pf,
+                                     const double* eta, const double* const* ref_out, double* partials, double dt,
+                                     void* stream);
+int32_t cloudsc2_nl_taylor_multi_f32(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t lev_stride,
+                                     const float* const* in, const float* const* in_i, int32_t nf, const double* pf,
+                                     const float* eta, const float* const* ref_out, double* partials, double dt,
+                                     void* stream);
+
+/* ---- validation-norm reductions (BUILD EXTENSIONS; the reference reduces on the host with NumPy).
+ * field_sums : per field f < nfields (<= 16), sum over nlev levels and nx columns of a[f] - b[f] (b == NULL: of a[f]);
+ *              the difference is formed in the field type, accumulated in double - TaylorTest.get_field_norm's
+ *              np.sum(field_nl_p - field_nl) and np.sum(field_tl) (tangent_linear/validation.py:250-261).  Workgroup w
+ *              writes partials[w * nfields + f]; `partials` holds cloudsc2_field_sums_blocks(nx, nlev) * nfields doubles.
+ * column_dots: out[c] (+)= sum over pairs p < npairs (<= 16) and nlev levels of a[p][k][c] * b[p][k][c] in double -
+ *              SymmetryTest.get_norm1 / get_norm2 (adjoint/validation.py:167-215); `accumulate` != 0 adds to out. */
+int32_t cloudsc2_field_sums_blocks(int32_t nx, int32_t nlev);
+int32_t cloudsc2_field_sums_f64(int32_t nx, int32_t nlev, int64_t lev_stride, int32_t nfields, const double* const* a,
+                                const double* const* b, double* partials, void* stream);
+int32_t cloudsc2_field_sums_f32(int32_t nx, int32_t nlev, int64_t lev_stride, int32_t nfields, const float* const* a,
+                                const float* const* b, double* partials, void* stream);
+int32_t cloudsc2_column_dots_f64(int32_t nx, int32_t nlev, int64_t lev_stride, int32_t npairs, const double* const* a,
+                                 const double* const* b, double* out, int32_t accumulate, void* stream);
+int32_t cloudsc2_column_dots_f32(int32_t nx, int32_t nlev, int64_t lev_stride, int32_t npairs, const float* const* a,
+                                 const float* const* b, double* out, int32_t accumulate, void* stream);
 
 /* ---- saturation : common/_stencils/saturation.py:23-42, called at common/saturation.py:67-76
  * (domain nx x 1 x nz: level nz of out_qsat is not written) */

@@ -1,11 +1,11 @@
 #!/bin/bash
 # A/B of the tuner's shift range over fresh processes of ONE lease: default grid (shifts 0/4/8/12 GB) vs shifts 0..32 GB in 4 GB steps
-# (CLOUDSC2_TUNE_SHIFTS_MB, a dev switch of storage.tune_placement).  Usage: bash profiles/tuner_ab.sh [extra bench args]
+# (bench.py --tune-shifts-mb, which passes shifts_mb / max_arena_bytes to storage.tune_placement).  Usage: bash profiles/tuner_ab.sh [extra bench args]
 mkdir -p gpurun_out/tuner_ab
 WIDE=0,4096,8192,12288,16384,20480,24576,28672,32768
 for i in 1 2 3 4; do
 for w in "" $WIDE; do
-CLOUDSC2_TUNE_SHIFTS_MB=$w python bench.py --steps 100 --warmup 20 --cpu-cols 0 --no-extra-rooflines "$@" 2>/dev/null | python -c "
+python bench.py --steps 100 --warmup 20 --cpu-cols 0 --no-extra-rooflines ${w:+--tune-shifts-mb $w} "$@" 2>/dev/null | python -c "
 import json,sys
 d=json.loads([l for l in sys.stdin if l.startswith('{')][0])
 p=d['placement']

@@ -58,6 +58,94 @@ def test_eight_ranks_config5_rehearsal():
     assert d["shard_check"]["col0_sum"] == 524288.0 * sum(range(8))          # ranks own columns [r * 524288, (r+1) * 524288)
 
 
+def test_eight_ranks_default_mode_rehearsal_carries_per_rank_times():
+    """The default (weak, fp64) mode at the driver's N = 8, rehearsed on gloo without kernels: 8 x 65 536 columns, and the
+    record carries every rank's own time (a straggler must be visible in the first real SCALE line)."""
+    p = _run("--gpus", "8", "--dry-run")
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.strip()][0])
+    assert d["n_gpus"] == 8 and d["rccl_ranks"] == 8 and d["scaling"] == "weak" and d["dtype"] == "f64"
+    assert d["config"]["columns_per_gpu"] == 65536 and d["config"]["columns_total"] == 8 * 65536
+    assert d["per_rank_ms"] == pytest.approx([1.0 * (r + 1) for r in range(8)]) and d["per_rank_ms_min_max"] == pytest.approx([1.0, 8.0])
+
+
+def test_every_rank_sizes_its_placement_arena_against_its_own_device(monkeypatch):
+    """under WORLD_SIZE = 8 a rank's `tune_placement` arena must be bounded by what ITS device has free
+    (60 %), whatever the other ranks do.  (a) the planning function never exceeds the bound, down to "does not fit";
+    (b) `tune_placement` asks `torch.cuda.mem_get_info` about the device it was given - bench.py hands it cuda:LOCAL_RANK."""
+    import numpy as np
+    import torch
+
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd import storage
+
+    slab = -(-(138 * 65536 * 8 + 65536) // (2 << 20)) * (2 << 20)
+    kw = dict(spacings=tuple(range(64)), staggers=(2304, 8448), shifts_mb=(0, 4096, 8192, 12288), wide_spacings=(),
+              wide_shifts_mb=(), max_arena_bytes=40 << 30, max_shift_spans=4.0)
+    for free in (288e9, 100e9, 30e9, 8e9, 4e9):
+        grid, need, _ = storage.plan_placement_grid(26, slab, int(free), **kw)
+        assert need <= 0.6 * free and need <= 40 << 30 and len(grid) >= 2, (free, need)
+        assert need >= 26 * slab                                   # and it does hold the 26 fields
+    with pytest.raises(RuntimeError, match="do not fit 60 %"):
+        storage.plan_placement_grid(26, slab, int(2e9), **kw)
+    asked = []
+
+    def fake_mem_get_info(dev):
+        asked.append(torch.device(dev))
+        return (int(2e9), int(288e9))                              # almost nothing free on that device
+
+    monkeypatch.setattr(torch.cuda, "mem_get_info", fake_mem_get_info)
+    with pytest.raises(RuntimeError, match="do not fit 60 %"):     # refused BEFORE anything is allocated
+        storage.tune_placement(65536, 137, np.float64, torch.device("cuda", 5), ["f%d" % i for i in range(26)], {}, None)
+    assert asked == [torch.device("cuda", 5)]
+    src = open(BENCH).read()
+    assert "torch.cuda.set_device(local_rank)" in src and 'device = torch.device("cuda", local_rank)' in src
+
+
+def test_concurrent_builds_of_eight_ranks_run_make_once(tmp_path):
+    """the N ranks of a multi-GPU bench all call `__graft_entry__.build()` at start-up; the file lock
+    must leave exactly ONE `make` of the HIP library when it is stale.  Rehearsed with 8 processes whose `make` and ISA
+    check are stand-ins that only log (a real rebuild takes minutes); the library's source hash is made stale for the
+    test and is valid again afterwards."""
+    import textwrap
+
+    lib = os.path.join(ROOT, "gt4py_dwarf_p_cloudsc2_tl_ad_amd", "libcloudsc2_hip.so")
+    if not os.path.exists(lib) or not os.path.exists(lib + ".srchash"):
+        pytest.skip("the library has not been built yet")
+    log = tmp_path / "make.log"
+    child = tmp_path / "child.py"
+    child.write_text(textwrap.dedent(f"""
+        import os, sys, time, types
+        sys.path.insert(0, {ROOT!r})
+        import __graft_entry__ as ge
+        real_run = ge.subprocess.run
+        def fake_run(cmd, *a, **kw):
+            if cmd[0] == "make" and "csrc" in cmd[2]:
+                with open({str(log)!r}, "a") as fh:
+                    fh.write("make %d\\n" % os.getpid())
+                time.sleep(0.5)                      # a build in progress: the other ranks are waiting for the lock
+                return types.SimpleNamespace(returncode=0)
+            return real_run(cmd, *a, **kw)
+        ge.subprocess.run = fake_run
+        fake = types.ModuleType("check_ring_isa")
+        fake.check_all = lambda *a, **k: {{"stand-in": True}}
+        sys.modules["check_ring_isa"] = fake
+        ge.build()
+        """))
+    saved = open(lib + ".srchash").read()
+    try:
+        with open(lib + ".srchash", "w") as fh:
+            fh.write("stale\n")
+        procs = [subprocess.Popen([sys.executable, str(child)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                 for _ in range(8)]
+        outs = [p.communicate(timeout=600) for p in procs]
+        assert all(p.returncode == 0 for p in procs), [o[1][-500:] for o in outs]
+        assert log.read_text().count("make") == 1, log.read_text()
+        assert open(lib + ".srchash").read() == saved        # marked as built from the (unchanged) sources again
+    finally:
+        with open(lib + ".srchash", "w") as fh:
+            fh.write(saved)
+
+
 def test_world_size_mismatch_and_bad_splits_are_refused():
     p = _run("--gpus", "2", "--dry-run", env={"WORLD_SIZE": "3", "RANK": "0"})
     assert p.returncode != 0 and "WORLD_SIZE=3" in (p.stderr + p.stdout)

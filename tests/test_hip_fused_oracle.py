@@ -1,0 +1,226 @@
+"""Build extensions held DIRECTLY against the oracle ("fused entry points are compared with other HIP kernels
+only"), plus the round-3 extensions: the validation-norm reduction kernels, the all-step-sizes Taylor kernel
+(`cloudsc2_nl_taylor_multi`) and the HIP-graph / fused-all modes of the harnesses.
+
+Oracle side (CPU, NumPy restatement): saturation + cloudsc2_nl on x, on x + f x_i (perturbed_state restated), and the
+sums the reference's TaylorTest forms from them (tangent_linear/validation.py:239-261).  Tolerances: tests/helpers.py."""
+import numpy as np
+import pytest
+
+from helpers import NL_IN, NL_OUT, assert_close, externals, nl_case, nlev_of, oracle, run_oracle_nl, to_device
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_perturbed(fields, fields_i, f2, eta, dt, ext):
+    """perturbed_state (common/_stencils/perturbed_state.py:75-91) then cloudsc2_nl, both by the oracle"""
+    dtype = fields["in_ap"].dtype.type
+    st = {k[3:]: v for k, v in fields.items()}
+    st_i = {k[3:]: fields_i[k + "_i"] for k in fields}
+    merged = dict(st)
+    merged.update({k + "_i": v for k, v in st_i.items()})
+    out = {k: np.zeros_like(v) for k, v in st.items()}
+    oracle.perturbed_state(merged, out, dtype(f2))
+    return run_oracle_nl({"in_" + k: v for k, v in out.items()}, eta, dt, ext)
+
+
+def _general_increments(fields, seed=5):
+    rng = np.random.default_rng(seed)
+    return {k + "_i": (v * rng.uniform(-0.02, 0.02, size=v.shape)).astype(v.dtype) for k, v in fields.items()}
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("nx", [333, 1024])     # register-prefetch path / LDS-ring path
+def test_fused_saturation_variant_matches_the_oracle(gpu, dtype, nx):
+    """`cloudsc2_nl_saturation` against oracle.saturation + oracle.cloudsc2_nl (not against the unfused HIP kernels)"""
+    import torch
+
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd import storage
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.stencils import compile_stencil
+
+    nz, ext = 137, externals()
+    fields, eta, dt = nl_case(nx, dtype=dtype, seed=11)      # in_qsat = oracle.saturation(ap, t)
+    want = run_oracle_nl(fields, eta, dt, ext)
+    dev = to_device({k: v for k, v in fields.items() if k != "in_qsat"}, gpu)
+    qsat = storage.zeros(nx, nz, dtype, gpu)
+    outs = {"out_" + n: storage.zeros(nx, nz, dtype, gpu) for n in NL_OUT}
+    compile_stencil("cloudsc2_nl_saturation", ext)(**dev, out_qsat=qsat, **outs, in_eta=torch.as_tensor(eta, device=gpu),
+                                                    dt=dt, origin=(0, 0, 0), domain=(nx, 1, nz + 1), validate_args=True,
+                                                    exec_info=None)
+    torch.cuda.synchronize()
+    assert_close("fused qsat", storage.klayout(qsat).cpu().numpy()[:nz], fields["in_qsat"][:nz], dtype)
+    for n in NL_OUT:
+        k = nlev_of(n, nz)
+        assert_close(f"fused-saturation out_{n}", storage.klayout(outs["out_" + n]).cpu().numpy()[:k], want[n][:k], dtype)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("sw", [dict(), dict(LEVAPLS2=True)])
+def test_fused_perturbation_variant_matches_the_oracle(gpu, dtype, sw):
+    """`cloudsc2_nl_perturbed` with GENERAL increments against oracle.perturbed_state + oracle.cloudsc2_nl"""
+    import torch
+
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd import storage
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.stencils import compile_stencil
+
+    nx, nz, f2 = 500, 137, 0.1
+    ext = externals(**sw)
+    fields, eta, dt = nl_case(nx, dtype=dtype, seed=12, ext=ext)
+    inc = _general_increments(fields)
+    want = _oracle_perturbed(fields, inc, f2, eta, dt, ext)
+    outs = {"out_" + n: storage.zeros(nx, nz, dtype, gpu) for n in NL_OUT}
+    compile_stencil("cloudsc2_nl_perturbed", ext)(**to_device(fields, gpu), **to_device(inc, gpu), **outs, f=f2,
+                                                   in_eta=torch.as_tensor(eta, device=gpu), dt=dt, origin=(0, 0, 0),
+                                                   domain=(nx, 1, nz + 1), validate_args=True, exec_info=None)
+    torch.cuda.synchronize()
+    for n in NL_OUT:
+        k = nlev_of(n, nz)
+        # fp32 with the evaporation block: the parity tests' own allowance for that block (tests/test_hip_nl.py)
+        mul = 4.0 if (sw and dtype == np.float32) else 1.0
+        assert_close(f"fused-perturbed out_{n}", storage.klayout(outs["out_" + n]).cpu().numpy()[:k], want[n][:k], dtype,
+                     rtol_mul=mul)
+
+
+def _oracle_taylor_sums(fields, inc, f2s, eta, dt, ext):
+    """sum(NL(x + f x_i) - NL(x)) per output field and step size, the differences formed in the field type
+    (np.sum(field_nl_p - field_nl), tangent_linear/validation.py:255), accumulated in double"""
+    base = run_oracle_nl(fields, eta, dt, ext)
+    rows, mags = [], []
+    for f2 in f2s:
+        p = _oracle_perturbed(fields, inc, f2, eta, dt, ext)
+        rows.append([float((p[n] - base[n]).sum(dtype=np.float64)) for n in NL_OUT])
+        mags.append([float(np.abs(p[n] - base[n]).sum(dtype=np.float64)) for n in NL_OUT])
+    return base, np.array(rows), np.array(mags)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("sw", [dict(), dict(LEVAPLS2=True)])
+def test_taylor_kernels_match_the_oracle_and_each_other(gpu, dtype, sw):
+    """`cloudsc2_nl_taylor` (one step size per launch) and `cloudsc2_nl_taylor_multi` (all step sizes, 5 per launch; 7
+    step sizes = launches of 5 and 2) against the ORACLE's sums, and against each other."""
+    import torch
+
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd import storage
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.stencils import compile_stencil, taylor_blocks
+
+    nx, nz = 700, 137
+    f2s = (0.5, 0.1, 1e-2, 1e-3, 1e-4, 1e-6, 1e-9)
+    ext = externals(**sw)
+    fields, eta, dt = nl_case(nx, dtype=dtype, seed=13, ext=ext)
+    inc = _general_increments(fields, seed=6)
+    base, want, mag = _oracle_taylor_sums(fields, inc, f2s, eta, dt, ext)
+    dev, dev_i = to_device(fields, gpu), to_device(inc, gpu)
+    com = dict(in_eta=torch.as_tensor(eta, device=gpu), dt=dt, origin=(0, 0, 0), domain=(nx, 1, nz + 1),
+               validate_args=True, exec_info=None)
+    ref = {"out_" + n: storage.zeros(nx, nz, dtype, gpu) for n in NL_OUT}
+    compile_stencil("cloudsc2_nl", ext)(**dev, **ref, **com)
+    refs = {"ref_" + n: ref["out_" + n] for n in NL_OUT}
+    keep = {k: v.clone() for k, v in ref.items()}
+    nb = taylor_blocks(nx)
+    single = torch.full((len(f2s), nb, len(NL_OUT)), float("nan"), dtype=torch.float64, device=gpu)
+    one = compile_stencil("cloudsc2_nl_taylor", ext)
+    for j, f2 in enumerate(f2s):
+        one(**dev, **dev_i, **refs, out_partials=single[j], f=f2, **com)
+    multi = torch.full((nb, len(f2s), len(NL_OUT)), float("nan"), dtype=torch.float64, device=gpu)
+    compile_stencil("cloudsc2_nl_taylor_multi", ext)(**dev, **dev_i, **refs, out_partials=multi, fs=f2s, **com)
+    torch.cuda.synchronize()
+    for k in ref:
+        assert torch.equal(ref[k], keep[k]), k                       # the reference outputs are read-only
+    got1 = single.sum(dim=1).cpu().numpy()
+    gotm = multi.sum(dim=0).cpu().numpy()
+    assert not np.isnan(gotm).any() and not np.isnan(got1).any()
+    # the two kernels run the same level function on the same words and reduce in the same order
+    assert np.allclose(gotm, got1, rtol=0, atol=1e-13 * mag.max()) if dtype == np.float64 else np.allclose(gotm, got1, rtol=1e-6, atol=1e-7 * mag.max())
+    # against the oracle: every difference carries the kernels' pointwise tolerance (helpers.TOL) on BOTH runs
+    tol = dict(rtol=1e-9, atol_rel=1e-11) if dtype == np.float64 else dict(rtol=2e-3, atol_rel=2e-4)
+    for fi, n in enumerate(NL_OUT):
+        scale = float(np.abs(base[n]).sum(dtype=np.float64))        # sum of |field|: what the pointwise bound adds up to
+        bound = 2.0 * (tol["rtol"] + tol["atol_rel"]) * scale + 1e-300
+        assert np.all(np.abs(gotm[:, fi] - want[:, fi]) <= bound), (n, gotm[:, fi], want[:, fi], bound)
+        assert np.all(np.abs(got1[:, fi] - want[:, fi]) <= bound), (n, got1[:, fi], want[:, fi], bound)
+    assert np.abs(want).max() > 0
+    # where the perturbation is far above rounding the sums agree to many digits (fp64)
+    if dtype == np.float64:
+        big = np.abs(want) > 1e-6 * mag.max()
+        assert np.all(np.abs(gotm[big] - want[big]) <= 1e-6 * np.abs(want[big]))
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_reduction_kernels_match_torch(gpu, dtype):
+    """`field_sums` / `column_dots` on aligned fields, on a column window of wider storages (lev_stride > nx) and on a
+    size that is no multiple of the workgroup; 10 and 16 fields; with and without subtrahend"""
+    import torch
+
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd import storage
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.reductions import column_dots, field_sums
+
+    td = storage.torch_dtype(dtype)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for nx, nz, pad in ((1000, 137, 0), (777, 20, 5), (64, 3, 0)):
+        wide = [torch.randn((nz + 1, nx + pad), generator=g, dtype=torch.float64).to(td).to(gpu) for _ in range(32)]
+        fields = [storage.logical_view(w[:, pad // 2: pad // 2 + nx]) for w in wide]
+        a, b = fields[:16], fields[16:]
+        for nf in (10, 16, 1):
+            got = field_sums(a[:nf], b[:nf]).cpu().numpy()
+            want = np.array([float((x - y).sum(dtype=torch.float64)) for x, y in zip(a[:nf], b[:nf])])
+            mag = np.array([float((x - y).abs().sum(dtype=torch.float64)) for x, y in zip(a[:nf], b[:nf])])
+            assert np.all(np.abs(got - want) <= 1e-13 * mag), (nx, nf)
+            got = field_sums(a[:nf]).cpu().numpy()
+            want = np.array([float(x.sum(dtype=torch.float64)) for x in a[:nf]])
+            assert np.all(np.abs(got - want) <= 1e-13 * np.array([float(x.abs().sum(dtype=torch.float64)) for x in a[:nf]]))
+        for pairs in (10, 16, 20):          # 20 pairs = two launches, the second accumulating
+            aa, bb = (a + b)[:pairs], (b + a)[:pairs]
+            got = column_dots(aa, bb).cpu().numpy()
+            want = sum((x[:, 0, :].double() * y[:, 0, :].double()).sum(dim=1) for x, y in zip(aa, bb)).cpu().numpy()
+            mag = sum((x[:, 0, :].double() * y[:, 0, :].double()).abs().sum(dim=1) for x, y in zip(aa, bb)).cpu().numpy()
+            assert got.shape == (nx,) and np.all(np.abs(got - want) <= 1e-13 * mag)
+        sq = column_dots(a[:10]).cpu().numpy()
+        want = sum((x[:, 0, :].double() ** 2).sum(dim=1) for x in a[:10]).cpu().numpy()
+        assert np.all(np.abs(sq - want) <= 1e-13 * want)
+    with pytest.raises(ValueError):
+        field_sums([fields[0]] * 17)
+
+
+def _taylor_ctx(argv):
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.drivers import run_taylor_test
+
+    return run_taylor_test.main(["--backend", "hip", "--num-runs", "2"] + argv)
+
+
+@pytest.mark.parametrize("precision", ["double", "single"])
+def test_taylor_driver_modes_agree(gpu, precision, capsys):
+    """plain, --fused, --fused-norms, --fused-all, --graph (alone and with the fused modes): the same norms (summation
+    order apart) and the same verdict of the reference's scoring rule, on the reader path and on distinct columns"""
+    for inp, cols in (("auto", 4096), ("synthetic", 3000)):
+        base = _taylor_ctx(["--num-cols", str(cols), "--input", inp, "--precision", precision])
+        verdict = [l for l in capsys.readouterr().out.splitlines() if l.startswith("The test ")]
+        for extra in (["--fused"], ["--fused-norms"], ["--fused-all"], ["--graph"], ["--fused", "--graph"],
+                      ["--fused-all", "--graph"]):
+            ctx = _taylor_ctx(["--num-cols", str(cols), "--input", inp, "--precision", precision] + extra)
+            out = [l for l in capsys.readouterr().out.splitlines() if l.startswith("The test ")]
+            # norms: ratios of sums; a different summation order moves them by rounding only while the perturbation is
+            # well above the noise floor of the field type (the last step sizes are noise in every mode)
+            n0, n1 = np.asarray(base["norms"]), np.asarray(ctx["norms"])
+            k = 6 if precision == "double" else 2
+            assert np.allclose(n1[:k], n0[:k], rtol=1e-7 if precision == "double" else 1e-3, atol=0), (extra, n0, n1)
+            if precision == "double":
+                assert out[0] == verdict[0], (extra, out, verdict)
+            assert ctx["passed"] == base["passed"] or precision == "single"
+
+
+def test_symmetry_driver_graph_mode(gpu, capsys):
+    """--graph replays the four launches of the timed call: the adjoint fields it leaves are those of the plain call"""
+    import torch
+
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.drivers import run_symmetry_test
+
+    a = run_symmetry_test.main(["--backend", "hip", "--num-cols", "4096", "--num-runs", "3"])
+    b = run_symmetry_test.main(["--backend", "hip", "--num-cols", "4096", "--num-runs", "3", "--graph"])
+    assert a["passed"] and b["passed"] and a["detail"] == b["detail"]
+    for dct in ("tends_ad", "diags_ad", "tends_tl", "diags_tl"):
+        da, db = getattr(a["harness"], dct), getattr(b["harness"], dct)
+        assert set(da) == set(db) and len(da) >= 4
+        for k in da:
+            if hasattr(da[k], "data"):
+                assert torch.equal(da[k].data, db[k].data), (dct, k)
+    assert "HOORAY" in capsys.readouterr().out

@@ -95,3 +95,54 @@ def test_tuner_sizes_its_arena_to_the_free_memory(gpu, monkeypatch):
     monkeypatch.setattr(torch.cuda, "mem_get_info", lambda dev=None: (slab, real[1]))
     with pytest.raises(RuntimeError, match="do not fit"):
         storage.tune_placement(nx, nz, np.float64, gpu, order, src, launch, budget_s=0.2)
+
+
+def test_a_failing_tuner_leaves_the_callers_state_untouched(monkeypatch, capsys):
+    """`tune_field_placement` re-points every DataArray at candidate placements while it tunes; when the
+    objective or the tuner raises, the DataArrays must be back on their ORIGINAL storages with their ORIGINAL contents
+    (candidate runs modify inout fields), the report must carry the reason and the drivers go on untuned.  CPU test: the
+    tuner is replaced by one that runs the objective once on a scratch placement and then fails."""
+    import torch
+
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd import storage
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.drivers import _common
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.framework.fields import DataArray
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.framework.grid import I, J, K
+
+    nx, nz = 8, 5
+    mk = lambda v: DataArray(storage.logical_view(torch.full((nz + 1, nx), float(v), dtype=torch.float64)), (I, J, K), "")  # noqa: E731
+    state = {"f_a": mk(1.0), "f_b": mk(2.0), "time": 0}
+    diags = {"f_b": state["f_b"], "f_c": mk(3.0)}               # f_b is shared by two dicts
+    before = {k: (v.data.data_ptr(), v.data.clone()) for k, v in {**state, **diags}.items() if hasattr(v, "data")}
+
+    def objective():                                            # an inout stencil: modifies what it is pointed at
+        state["f_a"].data.add_(10.0)
+        diags["f_c"].data.mul_(2.0)
+
+    def failing_tuner(nx_, nz_, dtype, device, order, sources, launch, **kw):
+        scratch = {n: storage.logical_view(sources[n].clone()) for n in order}
+        launch(scratch)                                         # the DataArrays now point into `scratch`
+        assert state["f_a"].data.data_ptr() == scratch[order[0]].data_ptr()
+        raise RuntimeError("tune_placement: 3 fields of 2097152 B do not fit 60 % of the free device memory")
+
+    monkeypatch.setattr(storage, "tune_placement", failing_tuner)
+    rep = _common.tune_field_placement([state, diags], objective, _any_device=True)
+    assert rep["fields"] == 3 and "do not fit" in rep["error"]
+    for k, v in {**state, **diags}.items():
+        if hasattr(v, "data"):
+            assert v.data.data_ptr() == before[k][0] and torch.equal(v.data, before[k][1]), k
+    assert state["f_b"] is diags["f_b"]
+    _common.report_placement(rep)
+    assert "NOT tuned" in capsys.readouterr().out
+
+    # an objective that raises by itself (a failing stencil) is handled the same way
+    def boom():
+        raise ValueError("cloudsc2_nl: output 'out_clc' overlaps 'in_t' in memory")
+
+    def plain_tuner(nx_, nz_, dtype, device, order, sources, launch, **kw):
+        launch({n: storage.logical_view(sources[n].clone()) for n in order})
+
+    monkeypatch.setattr(storage, "tune_placement", plain_tuner)
+    rep = _common.tune_field_placement([state, diags], boom, _any_device=True)
+    assert "overlaps" in rep["error"]
+    assert all(v.data.data_ptr() == before[k][0] for k, v in {**state, **diags}.items() if hasattr(v, "data"))

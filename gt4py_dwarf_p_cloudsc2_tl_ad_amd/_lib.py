@@ -32,6 +32,7 @@ EXPORTED_SYMBOLS = (
     "cloudsc2_field_sums_blocks", "cloudsc2_field_sums_f64", "cloudsc2_field_sums_f32",
     "cloudsc2_column_dots_f64", "cloudsc2_column_dots_f32",
     "cloudsc2_tl_f64", "cloudsc2_tl_f32",
+    "cloudsc2_tl_incremented_f64", "cloudsc2_tl_incremented_f32",
     "cloudsc2_ad_f64", "cloudsc2_ad_f32",
     "cloudsc2_saturation_f64", "cloudsc2_saturation_f32",
     "cloudsc2_state_increment_f64", "cloudsc2_state_increment_f32",
@@ -76,13 +77,16 @@ def _declare(lib: ctypes.CDLL) -> None:
         f.argtypes = common + [parr, parr, c_double, c_void_p, parr, c_void_p, c_double, c_void_p]
         f = getattr(lib, f"cloudsc2_nl_taylor_multi_{sfx}")
         f.restype = c_int32
-        f.argtypes = common + [parr, parr, c_int32, POINTER(c_double), c_void_p, parr, c_void_p, c_double, c_void_p]
+        f.argtypes = common + [parr, parr, c_double, c_int32, POINTER(c_double), c_void_p, parr, c_void_p, c_double, c_void_p]
         f = getattr(lib, f"cloudsc2_field_sums_{sfx}")
         f.restype = c_int32
         f.argtypes = [c_int32, c_int32, c_int64, c_int32, parr, parr, c_void_p, c_void_p]
         f = getattr(lib, f"cloudsc2_column_dots_{sfx}")
         f.restype = c_int32
         f.argtypes = [c_int32, c_int32, c_int64, c_int32, parr, parr, c_void_p, c_int32, c_void_p]
+        f = getattr(lib, f"cloudsc2_tl_incremented_{sfx}")
+        f.restype = c_int32
+        f.argtypes = common + [parr, c_double, c_void_p, parr, parr, c_double, c_void_p]
         for name in ("tl", "ad"):
             f = getattr(lib, f"cloudsc2_{name}_{sfx}")
             f.restype = c_int32

@@ -12,7 +12,7 @@ int launch_nl(const Cloudsc2Params&, int, int, int64_t, const T* const*, const T
               const T* const*, double, T*, double*);
 template <typename T>
 int launch_nl_taylor_multi(const Cloudsc2Params&, int, int, int64_t, const T* const*, const T* const*, int, const double*,
-                           const T*, const T* const*, double*, double, hipStream_t);
+                           const T*, const T* const*, double*, double, hipStream_t, double);
 int field_sums_blocks(int, int);
 template <typename T>
 int launch_field_sums(int, int, int64_t, int, const T* const*, const T* const*, double*, hipStream_t);
@@ -20,7 +20,7 @@ template <typename T>
 int launch_column_dots(int, int, int64_t, int, const T* const*, const T* const*, double*, int, hipStream_t);
 template <typename T>
 int launch_tl(const Cloudsc2Params&, int, int, int64_t, const T* const*, const T* const*, const T*, T* const*,
-              T* const*, double, hipStream_t);
+              T* const*, double, hipStream_t, double);
 template <typename T>
 int launch_ad(const Cloudsc2Params&, int, int, int64_t, const T* const*, const T* const*, const T*, T* const*,
               T* const*, double, hipStream_t);
@@ -133,13 +133,14 @@ int nl_taylor_impl(const char* fn, const Cloudsc2Params* p, int32_t nx, int32_t 
 // The Taylor test's perturbed runs, several step sizes per launch (build extension): see include/cloudsc2_hip.h.
 template <typename T>
 int nl_taylor_multi_impl(const char* fn, const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls, const T* const* in,
-                         const T* const* in_i, int32_t nf, const double* pf, const T* eta, const T* const* ref_out,
-                         double* partials, double dt, void* stream) {
+                         const T* const* in_i, double inc_f, int32_t nf, const double* pf, const T* eta,
+                         const T* const* ref_out, double* partials, double dt, void* stream) {
     if (int rc = check_common(fn, p, nx, nz, ls)) return rc;
     if (nf < 0 || nf > 64) return fail(CLOUDSC2_E_ARG, "%s: nf=%d outside [0, 64]", fn, nf);
     if (nx == 0 || nf == 0) return CLOUDSC2_OK;
     if (int rc = check_ptrs(fn, "in", in, NL_NUM_IN)) return rc;
-    if (int rc = check_ptrs(fn, "in_i", in_i, NL_NUM_IN)) return rc;
+    if (in_i)      // NULL: the increments are formed in the kernel as inc_f * in (state_increment fused in)
+        if (int rc = check_ptrs(fn, "in_i", in_i, NL_NUM_IN)) return rc;
     if (int rc = check_ptrs(fn, "ref_out", ref_out, NL_NUM_OUT)) return rc;
     if (!eta) return fail(CLOUDSC2_E_ARG, "%s: eta is NULL", fn);
     if (!pf) return fail(CLOUDSC2_E_ARG, "%s: pf is NULL", fn);
@@ -148,7 +149,7 @@ int nl_taylor_multi_impl(const char* fn, const Cloudsc2Params* p, int32_t nx, in
     if (!(dt > 0.0)) return fail(CLOUDSC2_E_ARG, "%s: dt=%g must be > 0", fn, dt);
     if (nz > 2000) return fail(CLOUDSC2_E_UNSUPPORTED, "%s: nz=%d: the level table and the running sums must share the LDS", fn, nz);
     return launched(fn, cs2::launch_nl_taylor_multi<T>(*p, nx, nz, ls, in, in_i, nf, pf, eta, ref_out, partials, dt,
-                                                       static_cast<hipStream_t>(stream)));
+                                                       static_cast<hipStream_t>(stream), inc_f));
 }
 
 template <typename T>
@@ -176,20 +177,24 @@ int dots_impl(const char* fn, int32_t nx, int32_t nlev, int64_t ls, int32_t np, 
     return launched(fn, cs2::launch_column_dots<T>(nx, nlev, ls, np, a, b, out, accumulate, static_cast<hipStream_t>(stream)));
 }
 
+// `fused_inc`: the state_increment-fused variant (cloudsc2_tl_incremented_*): in_i is absent, perturbations = inc_f * in
 template <typename T>
 int tl_impl(const char* fn, const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls, const T* const* in,
-            const T* const* in_i, const T* eta, T* const* out, T* const* out_i, double dt, void* stream) {
+            const T* const* in_i, const T* eta, T* const* out, T* const* out_i, double dt, void* stream,
+            bool fused_inc = false, double inc_f = 0.0) {
     if (int rc = check_common(fn, p, nx, nz, ls)) return rc;
     if (nx == 0) return CLOUDSC2_OK;   // empty call: nothing to check or launch (zero-size tensors carry NULL pointers)
     if (int rc = check_ptrs(fn, "in", in, NL_NUM_IN)) return rc;
-    if (int rc = check_ptrs(fn, "in_i", in_i, NL_NUM_IN)) return rc;
+    if (!fused_inc)
+        if (int rc = check_ptrs(fn, "in_i", in_i, NL_NUM_IN)) return rc;
     if (int rc = check_ptrs(fn, "out", const_cast<const T* const*>(out), NL_NUM_OUT)) return rc;
     if (int rc = check_ptrs(fn, "out_i", const_cast<const T* const*>(out_i), NL_NUM_OUT)) return rc;
     if (!eta) return fail(CLOUDSC2_E_ARG, "%s: eta is NULL", fn);
     if (p->ICALL != 0) return fail(CLOUDSC2_E_UNSUPPORTED, "%s: ICALL=%d unsupported", fn, p->ICALL);
     if (!(dt > 0.0)) return fail(CLOUDSC2_E_ARG, "%s: dt=%g must be > 0", fn, dt);
     if (p->NLEV != nz) return fail(CLOUDSC2_E_ARG, "%s: NLEV=%d != nz=%d", fn, p->NLEV, nz);
-    return launched(fn, cs2::launch_tl<T>(*p, nx, nz, ls, in, in_i, eta, out, out_i, dt, static_cast<hipStream_t>(stream)));
+    return launched(fn, cs2::launch_tl<T>(*p, nx, nz, ls, in, fused_inc ? nullptr : in_i, eta, out, out_i, dt,
+                                          static_cast<hipStream_t>(stream), inc_f));
 }
 
 template <typename T>
@@ -289,15 +294,15 @@ int32_t cloudsc2_nl_taylor_f32(const Cloudsc2Params* p, int32_t nx, int32_t nz, 
     return nl_taylor_impl<float>("cloudsc2_nl_taylor_f32", p, nx, nz, ls, in, in_i, pf, eta, ref_out, partials, dt, stream);
 }
 int32_t cloudsc2_nl_taylor_multi_f64(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls, const double* const* in,
-                                     const double* const* in_i, int32_t nf, const double* pf, const double* eta,
+                                     const double* const* in_i, double inc_f, int32_t nf, const double* pf, const double* eta,
                                      const double* const* ref_out, double* partials, double dt, void* stream) {
-    return nl_taylor_multi_impl<double>("cloudsc2_nl_taylor_multi_f64", p, nx, nz, ls, in, in_i, nf, pf, eta, ref_out,
+    return nl_taylor_multi_impl<double>("cloudsc2_nl_taylor_multi_f64", p, nx, nz, ls, in, in_i, inc_f, nf, pf, eta, ref_out,
                                         partials, dt, stream);
 }
 int32_t cloudsc2_nl_taylor_multi_f32(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls, const float* const* in,
-                                     const float* const* in_i, int32_t nf, const double* pf, const float* eta,
+                                     const float* const* in_i, double inc_f, int32_t nf, const double* pf, const float* eta,
                                      const float* const* ref_out, double* partials, double dt, void* stream) {
-    return nl_taylor_multi_impl<float>("cloudsc2_nl_taylor_multi_f32", p, nx, nz, ls, in, in_i, nf, pf, eta, ref_out,
+    return nl_taylor_multi_impl<float>("cloudsc2_nl_taylor_multi_f32", p, nx, nz, ls, in, in_i, inc_f, nf, pf, eta, ref_out,
                                        partials, dt, stream);
 }
 int32_t cloudsc2_field_sums_blocks(int32_t nx, int32_t nlev) { return cs2::field_sums_blocks(nx, nlev); }
@@ -326,6 +331,16 @@ int32_t cloudsc2_tl_f32(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t
                         const float* const* in_i, const float* eta, float* const* out, float* const* out_i,
                         double dt, void* stream) {
     return tl_impl<float>("cloudsc2_tl_f32", p, nx, nz, ls, in, in_i, eta, out, out_i, dt, stream);
+}
+int32_t cloudsc2_tl_incremented_f64(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls, const double* const* in,
+                                    double f, const double* eta, double* const* out, double* const* out_i, double dt,
+                                    void* stream) {
+    return tl_impl<double>("cloudsc2_tl_incremented_f64", p, nx, nz, ls, in, nullptr, eta, out, out_i, dt, stream, true, f);
+}
+int32_t cloudsc2_tl_incremented_f32(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls, const float* const* in,
+                                    double f, const float* eta, float* const* out, float* const* out_i, double dt,
+                                    void* stream) {
+    return tl_impl<float>("cloudsc2_tl_incremented_f32", p, nx, nz, ls, in, nullptr, eta, out, out_i, dt, stream, true, f);
 }
 int32_t cloudsc2_ad_f64(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls, const double* const* in,
                         const double* const* in_adj, const double* eta, double* const* out,

@@ -126,6 +126,14 @@ template <> __device__ __forceinline__ double fexp<double>(const ExpK<double>& k
     return __builtin_ldexp(p, static_cast<int>(n));
 }
 template <> __device__ __forceinline__ float fexp<float>(const ExpK<float>&, float x) { return expf(x); }
+// A product that is ROUNDED as a product, whatever consumes it: contraction is switched off for this multiply, so the
+// backend cannot fold it into a following add / subtract as an fma.  The kernels that fuse `state_increment` in
+// (x_i = f * x formed in registers instead of loaded) use it to reproduce the stored products bit for bit.
+template <typename T>
+__device__ __forceinline__ T rounded_product(T f, T x) {
+#pragma clang fp contract(off)
+    return f * x;
+}
 template <typename T> __device__ __forceinline__ T rmin(T a, T b) { return a < b ? a : b; }
 template <typename T> __device__ __forceinline__ T rmax(T a, T b) { return a > b ? a : b; }
 template <typename T> __device__ __forceinline__ T sq(T x) { return x * x; }

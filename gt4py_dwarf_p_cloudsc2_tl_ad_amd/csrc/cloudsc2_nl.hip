@@ -935,17 +935,21 @@ template int launch_nl<float>(const Cloudsc2Params&, int, int, int64_t, const fl
 template <typename T, int NF>
 struct PFs { T f[NF]; };
 
-template <typename T, int NF>
+// INC (here and in the kernel): the increment fields are not read but formed as finc * state (state_increment fused in,
+// common/_stencils/state_increment.py:61-80 - the same products the stand-alone increment kernel stores)
+template <typename T, int NF, bool INC>
 __device__ __forceinline__ void trpaus_prescan_multi(const T* __restrict__ pt, const T* __restrict__ ptt,
                                                      const T* __restrict__ pt_i, const T* __restrict__ ptt_i, uint32_t lsb,
                                                      uint32_t colb, T dt, const T* s_eta, int klo, int khi,
-                                                     const PFs<T, NF>& pf, T (&trpaus)[NF]) {
+                                                     const PFs<T, NF>& pf, T finc, T (&trpaus)[NF]) {
 #pragma unroll
     for (int j = 0; j < NF; ++j) trpaus[j] = T(0.1);
     if (klo > khi) return;
     constexpr int CH = 8;
     const uint32_t o0 = uint32_t(klo) * lsb + colb;
-    const T a0 = ldg(pt, o0), b0 = ldg(ptt, o0), ai0 = ldg(pt_i, o0), bi0 = ldg(ptt_i, o0);
+    const T a0 = ldg(pt, o0), b0 = ldg(ptt, o0);
+    const T ai0 = INC ? rounded_product<T>(finc, a0) : ldg(pt_i, o0);
+    const T bi0 = INC ? rounded_product<T>(finc, b0) : ldg(ptt_i, o0);
     T tk[NF];
 #pragma unroll
     for (int j = 0; j < NF; ++j) {
@@ -961,8 +965,17 @@ __device__ __forceinline__ void trpaus_prescan_multi(const T* __restrict__ pt, c
             const uint32_t oi = uint32_t(kk) * lsb + colb;
             a[i] = ldg(pt, oi);
             b[i] = ldg(ptt, oi);
-            ai[i] = ldg(pt_i, oi);
-            bi[i] = ldg(ptt_i, oi);
+            if constexpr (!INC) {
+                ai[i] = ldg(pt_i, oi);
+                bi[i] = ldg(ptt_i, oi);
+            }
+        }
+        if constexpr (INC) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                ai[i] = rounded_product<T>(finc, a[i]);
+                bi[i] = rounded_product<T>(finc, b[i]);
+            }
         }
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
@@ -984,6 +997,17 @@ __device__ __forceinline__ void trpaus_prescan_multi(const T* __restrict__ pt, c
 }
 
 template <typename T>
+__device__ __forceinline__ NLIn<T> nl_increment(const NLIn<T>& a, T f, bool zero_supsat) {
+    NLIn<T> x;   // rounded_product: the STORED products of the increment kernel, never half of an fma (nl_perturb's x + f2 * x_i)
+#define CS2_P(m) x.m = rounded_product<T>(f, a.m)
+    CS2_P(ap); CS2_P(aph1); CS2_P(lu1); CS2_P(lude); CS2_P(mfd); CS2_P(mfu); CS2_P(q); CS2_P(qi); CS2_P(ql); CS2_P(qsat);
+    CS2_P(t); CS2_P(tq); CS2_P(tqi); CS2_P(tql); CS2_P(tt);
+#undef CS2_P
+    x.supsat = zero_supsat ? T(0.0) : rounded_product<T>(f, a.supsat);
+    return x;
+}
+
+template <typename T>
 __device__ __forceinline__ void nl_load_refs(const CPtrs<T, NL_NUM_OUT>& ref, uint32_t lsb, uint32_t o, T (&r)[NL_NUM_OUT]) {
 #pragma unroll
     for (int f = 0; f < NL_NUM_OUT; ++f) {
@@ -992,11 +1016,11 @@ __device__ __forceinline__ void nl_load_refs(const CPtrs<T, NL_NUM_OUT>& ref, ui
     }
 }
 
-template <typename T, bool EVAP, bool LIN, bool PINK, int NF>
+template <typename T, bool EVAP, bool LIN, bool PINK, int NF, bool INC>
 __global__ void __launch_bounds__(kColBlock, 1)
 nl_taylor_multi_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, NL_NUM_IN> in,
                        CPtrs<T, NL_NUM_IN> in_i, CPtrs<T, NL_NUM_OUT> ref, const T* __restrict__ eta, T dt, PFs<T, NF> pf,
-                       double* __restrict__ partials, int nf_total, int f0) {
+                       double* __restrict__ partials, int nf_total, int f0, T finc, int zero_supsat_i) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     T* s_eta = reinterpret_cast<T*>(smem_raw);
     T* s_scalm = s_eta + (nz + 1);
@@ -1027,17 +1051,18 @@ nl_taylor_multi_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t 
     const uint32_t colb = uint32_t(col) * uint32_t(sizeof(T));
 
     T trpaus[NF];
-    trpaus_prescan_multi<T, NF>(in.p[NL_IN_T], in.p[NL_IN_TND_CML_T], in_i.p[NL_IN_T], in_i.p[NL_IN_TND_CML_T], lsb, colb, dt,
-                                s_eta, klo, khi, pf, trpaus);
+    trpaus_prescan_multi<T, NF, INC>(in.p[NL_IN_T], in.p[NL_IN_TND_CML_T], in_i.p[NL_IN_T], in_i.p[NL_IN_TND_CML_T], lsb, colb,
+                                     dt, s_eta, klo, khi, pf, finc, trpaus);
     CrhCol<T> crh[NF];
     NLCarry<T> c[NF];
     T aph_s[NF];
     {
-        const T aph0 = ldg(in.p[NL_IN_APH], colb), aph0_i = ldg(in_i.p[NL_IN_APH], colb);
+        const T aph0 = ldg(in.p[NL_IN_APH], colb);
+        const T aph0_i = INC ? rounded_product<T>(finc, aph0) : ldg(in_i.p[NL_IN_APH], colb);
         T aphs = T(1.0), aphs_i = T(0.0);
         if constexpr (EVAP) {
             aphs = ldg(in.p[NL_IN_APH], uint32_t(nz) * lsb + colb);
-            aphs_i = ldg(in_i.p[NL_IN_APH], uint32_t(nz) * lsb + colb);
+            aphs_i = INC ? rounded_product<T>(finc, aphs) : ldg(in_i.p[NL_IN_APH], uint32_t(nz) * lsb + colb);
         }
 #pragma unroll
         for (int j = 0; j < NF; ++j) {
@@ -1051,13 +1076,13 @@ nl_taylor_multi_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t 
     }
 
     // register double buffer: level k+1's 42 words are requested before level k's NF evaluations
-    NLIn<T> bufa[2], bufb[2];
+    NLIn<T> bufa[2], bufb[INC ? 1 : 2];
     T bufr[2][NL_NUM_OUT];
     bufa[0] = nl_load<T, false>(in, lsb, colb);
-    bufb[0] = nl_load<T, false>(in_i, lsb, colb);
+    if constexpr (!INC) bufb[0] = nl_load<T, false>(in_i, lsb, colb);
     nl_load_refs<T>(ref, lsb, colb, bufr[0]);
     bufa[1] = bufa[0];
-    bufb[1] = bufb[0];
+    if constexpr (!INC) bufb[1] = bufb[0];
 #pragma unroll
     for (int f = 0; f < NL_NUM_OUT; ++f) bufr[1][f] = bufr[0][f];
     uint32_t o = colb;
@@ -1068,13 +1093,16 @@ nl_taylor_multi_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t 
             if (k < nz) {
                 if (k + 1 < nz) {
                     bufa[s ^ 1] = nl_load<T, false>(in, lsb, o + lsb);
-                    bufb[s ^ 1] = nl_load<T, false>(in_i, lsb, o + lsb);
+                    if constexpr (!INC) bufb[s ^ 1] = nl_load<T, false>(in_i, lsb, o + lsb);
                     nl_load_refs<T>(ref, lsb, o + lsb, bufr[s ^ 1]);
                 }
                 const T eta_k = s_eta[k], scalm_k = s_scalm[k];
+                NLIn<T> inc_k;
+                if constexpr (INC) inc_k = nl_increment<T>(bufa[s], finc, zero_supsat_i != 0);
+                const NLIn<T>& xi = INC ? inc_k : bufb[INC ? 0 : s];
 #pragma unroll
                 for (int j = 0; j < NF; ++j) {
-                    const NLIn<T> x = nl_perturb<T>(bufa[s], bufb[s], pf.f[j]);
+                    const NLIn<T> x = nl_perturb<T>(bufa[s], xi, pf.f[j]);
                     const NLOut<T> r = nl_level<T, EVAP, LIN>(e, kc, xk, x, eta_k, scalm_k, crh[j], dt, aph_s[j], c[j]);
                     if (live) {
                         double* const a = s_acc + j * NL_NUM_OUT * kColBlock;
@@ -1119,11 +1147,14 @@ nl_taylor_multi_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t 
 template <typename T>
 int launch_nl_taylor_multi(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* const* in, const T* const* in_i,
                            int nf, const double* pfs, const T* eta, const T* const* ref_out, double* partials, double dt,
-                           hipStream_t stream) {
+                           hipStream_t stream, double inc_f) {
+    const bool inc = in_i == nullptr;      // fused state_increment: in_i = T(inc_f) * in, formed in the kernel
+    const T tinc = static_cast<T>(inc_f);
+    const int zsi = p.IGNORE_SUPSAT ? 1 : 0;
     const Ext<T> e = make_ext<T>(p);
     CPtrs<T, NL_NUM_IN> ci, cii;
     CPtrs<T, NL_NUM_OUT> cr;
-    for (int i = 0; i < NL_NUM_IN; ++i) { ci.p[i] = in[i]; cii.p[i] = in_i[i]; }
+    for (int i = 0; i < NL_NUM_IN; ++i) { ci.p[i] = in[i]; cii.p[i] = inc ? nullptr : in_i[i]; }
     for (int i = 0; i < NL_NUM_OUT; ++i) cr.p[i] = ref_out[i];
     const dim3 grid((nx + kColBlock - 1) / kColBlock), block(kColBlock);
     const bool evap = p.LEVAPLS2 || p.LDRAIN1D;
@@ -1137,7 +1168,11 @@ int launch_nl_taylor_multi(const Cloudsc2Params& p, int nx, int nz, int64_t ls, 
     const size_t tab = (2 * size_t(nz + 1) * sizeof(T) + 15) & ~size_t(15);
 #define CS2_NLM_LAUNCH(EV, LN, NFV)                                                                                    \
     do {                                                                                                                \
-        auto kern = nl_taylor_multi_kernel<T, EV, LN, sizeof(T) == 8, NFV>;                                             \
+        if (inc) CS2_NLM_LAUNCH_I(EV, LN, NFV, true); else CS2_NLM_LAUNCH_I(EV, LN, NFV, false);                        \
+    } while (0)
+#define CS2_NLM_LAUNCH_I(EV, LN, NFV, INCV)                                                                            \
+    do {                                                                                                                \
+        auto kern = nl_taylor_multi_kernel<T, EV, LN, sizeof(T) == 8, NFV, INCV>;                                       \
         const size_t smem = tab + size_t(NFV) * NL_NUM_OUT * kColBlock * sizeof(double);                                \
         if (smem + sizeof(double) * (kColBlock / 64) * NFV * NL_NUM_OUT > size_t(160) * 1024) return -2;                \
         static std::atomic<size_t> attr_set[kMaxDevices] = {};                                                          \
@@ -1145,7 +1180,7 @@ int launch_nl_taylor_multi(const Cloudsc2Params& p, int nx, int nz, int64_t ls, 
         PFs<T, NFV> pf;                                                                                                 \
         for (int j = 0; j < NFV; ++j) pf.f[j] = static_cast<T>(pfs[f0 + j]);                                            \
         hipLaunchKernelGGL(kern, grid, block, smem, stream, e, kc, xk, nx, nz, ls, ci, cii, cr, eta, tdt, pf, partials, \
-                           nf, f0);                                                                                     \
+                           nf, f0, tinc, zsi);                                                                          \
     } while (0)
 #define CS2_NLM_FLAGS(NFV)                                            \
     do {                                                              \
@@ -1163,15 +1198,16 @@ int launch_nl_taylor_multi(const Cloudsc2Params& p, int nx, int nz, int64_t ls, 
     }
 #undef CS2_NLM_FLAGS
 #undef CS2_NLM_LAUNCH
+#undef CS2_NLM_LAUNCH_I
     note_kernel("cs2::nl_taylor_multi_kernel");
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 template int launch_nl_taylor_multi<double>(const Cloudsc2Params&, int, int, int64_t, const double* const*,
                                             const double* const*, int, const double*, const double*, const double* const*,
-                                            double*, double, hipStream_t);
+                                            double*, double, hipStream_t, double);
 template int launch_nl_taylor_multi<float>(const Cloudsc2Params&, int, int, int64_t, const float* const*,
                                            const float* const*, int, const double*, const float*, const float* const*,
-                                           double*, double, hipStream_t);
+                                           double*, double, hipStream_t, double);
 
 }  // namespace cs2

@@ -44,6 +44,20 @@ __device__ __forceinline__ TLIn<T> tl_load(const CPtrs<T, NL_NUM_IN>& in, uint32
     return x;
 }
 
+// state_increment (common/_stencils/state_increment.py:61-80) applied on the fly: x_i = f * x, supsat_i = 0 with
+// IGNORE_SUPSAT - the very products the stand-alone increment kernel stores (cloudsc2_aux.hip), so the fused variant
+// (INC, C ABI cloudsc2_tl_incremented_*) feeds the level function exactly the words the separate calls would load.
+template <typename T>
+__device__ __forceinline__ TLIn<T> tl_increment(const TLIn<T>& x, T f, bool zero_supsat) {
+    TLIn<T> y;   // rounded_product: these are the STORED products of the increment kernel, never half of an fma
+#define CS2_P(m) y.m = rounded_product<T>(f, x.m)
+    CS2_P(ap); CS2_P(aph1); CS2_P(lu1); CS2_P(lude); CS2_P(mfd); CS2_P(mfu); CS2_P(q); CS2_P(qi); CS2_P(ql); CS2_P(qsat);
+    CS2_P(t); CS2_P(tq); CS2_P(tqi); CS2_P(tql); CS2_P(tt);
+#undef CS2_P
+    y.supsat = zero_supsat ? T(0.0) : rounded_product<T>(f, x.supsat);
+    return y;
+}
+
 template <typename T>
 struct TLCarry {
     T rfl, rfl_i, sfl, sfl_i, covptot, covptot_i, aph_k, aph_k_i;
@@ -543,11 +557,13 @@ __device__ __forceinline__ void tl_store(const MPtrs<T, NL_NUM_OUT>& out, const 
     stg(out_i.p[NL_OUT_FHPSN], i + lsb, -o.sfln_i * e.RLSTT);
 }
 
-template <typename T, bool REG, bool EVAP>
+// INC: the perturbation fields are not read but formed as finc * in (state_increment fused in, see tl_increment):
+// 16 input streams instead of 32, no landing buffer for the second 16.
+template <typename T, bool REG, bool EVAP, bool INC = false>
 __global__ void __launch_bounds__(kColBlock)
 tl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, NL_NUM_IN> in,
           CPtrs<T, NL_NUM_IN> in_i, const T* __restrict__ eta, MPtrs<T, NL_NUM_OUT> out, MPtrs<T, NL_NUM_OUT> out_i,
-          T dt) {
+          T dt, T finc, int zero_supsat_i) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     T* s_eta = reinterpret_cast<T*>(smem_raw);
     T* s_scalm = s_eta + (nz + 1);
@@ -577,9 +593,14 @@ tl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
     TLCarry<T> c;
     c.rfl = c.rfl_i = c.sfl = c.sfl_i = c.covptot = c.covptot_i = T(0.0);
     c.aph_k = ldg(in.p[NL_IN_APH], colb);
-    c.aph_k_i = ldg(in_i.p[NL_IN_APH], colb);
     c.aph_s = EVAP ? ldg(in.p[NL_IN_APH], uint32_t(nz) * lsb + colb) : T(1.0);
-    c.aph_s_i = EVAP ? ldg(in_i.p[NL_IN_APH], uint32_t(nz) * lsb + colb) : T(0.0);
+    if constexpr (INC) {
+        c.aph_k_i = rounded_product<T>(finc, c.aph_k);
+        c.aph_s_i = EVAP ? rounded_product<T>(finc, c.aph_s) : T(0.0);
+    } else {
+        c.aph_k_i = ldg(in_i.p[NL_IN_APH], colb);
+        c.aph_s_i = EVAP ? ldg(in_i.p[NL_IN_APH], uint32_t(nz) * lsb + colb) : T(0.0);
+    }
 
     if (live) {
         // :757-765
@@ -594,18 +615,31 @@ tl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
     }
 
     uint32_t o = colb;
-    TLIn<T> xa = tl_load<T>(in, lsb, o), ya = tl_load<T>(in_i, lsb, o);
-    for (int k = 0; k < nz; ++k) {
-        TLIn<T> xn = xa, yn = ya;
-        if (k + 1 < nz) {
-            xn = tl_load<T>(in, lsb, o + lsb);
-            yn = tl_load<T>(in_i, lsb, o + lsb);
+    if constexpr (INC) {
+        TLIn<T> xa = tl_load<T>(in, lsb, o);
+        for (int k = 0; k < nz; ++k) {
+            TLIn<T> xn = xa;
+            if (k + 1 < nz) xn = tl_load<T>(in, lsb, o + lsb);
+            const TLIn<T> ya = tl_increment<T>(xa, finc, zero_supsat_i != 0);
+            const TLOut<T> r = tl_level<T, REG, EVAP>(e, kc, xk, xa, ya, k, s_eta[k], s_scalm[k], crh, dt, c);
+            if (live) tl_store<T>(out, out_i, e, lsb, o, r);
+            xa = xn;
+            o += lsb;
         }
-        const TLOut<T> r = tl_level<T, REG, EVAP>(e, kc, xk, xa, ya, k, s_eta[k], s_scalm[k], crh, dt, c);
-        if (live) tl_store<T>(out, out_i, e, lsb, o, r);
-        xa = xn;
-        ya = yn;
-        o += lsb;
+    } else {
+        TLIn<T> xa = tl_load<T>(in, lsb, o), ya = tl_load<T>(in_i, lsb, o);
+        for (int k = 0; k < nz; ++k) {
+            TLIn<T> xn = xa, yn = ya;
+            if (k + 1 < nz) {
+                xn = tl_load<T>(in, lsb, o + lsb);
+                yn = tl_load<T>(in_i, lsb, o + lsb);
+            }
+            const TLOut<T> r = tl_level<T, REG, EVAP>(e, kc, xk, xa, ya, k, s_eta[k], s_scalm[k], crh, dt, c);
+            if (live) tl_store<T>(out, out_i, e, lsb, o, r);
+            xa = xn;
+            ya = yn;
+            o += lsb;
+        }
     }
 }
 
@@ -836,12 +870,16 @@ tl_ring_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtr
 
 template <typename T>
 int launch_tl(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* const* in, const T* const* in_i,
-              const T* eta, T* const* out, T* const* out_i, double dt, hipStream_t stream) {
+              const T* eta, T* const* out, T* const* out_i, double dt, hipStream_t stream, double inc_f) {
+    // in_i == nullptr: the fused state_increment variant - perturbations formed in the kernel as T(inc_f) * in
+    const bool inc = in_i == nullptr;
+    const T tinc = static_cast<T>(inc_f);
+    const int zsi = p.IGNORE_SUPSAT ? 1 : 0;
     const bool evap = p.LEVAPLS2 || p.LDRAIN1D;
     const Ext<T> e = make_ext<T>(p);
     CPtrs<T, NL_NUM_IN> ci, cii;
     MPtrs<T, NL_NUM_OUT> co, coi;
-    for (int i = 0; i < NL_NUM_IN; ++i) { ci.p[i] = in[i]; cii.p[i] = in_i[i]; }
+    for (int i = 0; i < NL_NUM_IN; ++i) { ci.p[i] = in[i]; cii.p[i] = inc ? nullptr : in_i[i]; }
     for (int i = 0; i < NL_NUM_OUT; ++i) { co.p[i] = out[i]; coi.p[i] = out_i[i]; }
     const dim3 grid((nx + kColBlock - 1) / kColBlock), block(kColBlock);
     const size_t smem = 2 * size_t(nz + 1) * sizeof(T);
@@ -853,7 +891,7 @@ int launch_tl(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
     if constexpr (kRing >= 2) {
         // LDS-ring variant: whole waves, 16-byte aligned rows of every input field (the DMA moves 16 B per lane)
         using G = TLRingGeom<T>;
-        bool ring = nx % 64 == 0 && nz >= kRing && (ls * int64_t(sizeof(T))) % 16 == 0;
+        bool ring = !inc && nx % 64 == 0 && nz >= kRing && (ls * int64_t(sizeof(T))) % 16 == 0;
         for (int i = 0; i < NL_NUM_IN && ring; ++i)
             ring = reinterpret_cast<uintptr_t>(in[i]) % 16 == 0 && reinterpret_cast<uintptr_t>(in_i[i]) % 16 == 0;
         const size_t tab = (2 * size_t(nz + 1) * sizeof(T) + 1023) & ~size_t(1023);
@@ -895,22 +933,27 @@ int launch_tl(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
             return hipGetLastError() == hipSuccess ? 0 : -1;
         }
     }
-#define CS2_TL_LAUNCH(REG, EVAP)                                                                                     \
-    hipLaunchKernelGGL((tl_kernel<T, REG, EVAP>), grid, block, smem, stream, e, kc, xk, nx, nz, ls, ci, cii, eta, co, \
-                       coi, tdt)
+#define CS2_TL_LAUNCH(REG, EVAP, INCV)                                                                                 \
+    hipLaunchKernelGGL((tl_kernel<T, REG, EVAP, INCV>), grid, block, smem, stream, e, kc, xk, nx, nz, ls, ci, cii, eta, \
+                       co, coi, tdt, tinc, zsi)
+#define CS2_TL_LAUNCH_I(REG, EVAP)                                               \
+    do {                                                                         \
+        if (inc) CS2_TL_LAUNCH(REG, EVAP, true); else CS2_TL_LAUNCH(REG, EVAP, false); \
+    } while (0)
     if (p.LREGCL) {
-        if (evap) CS2_TL_LAUNCH(true, true); else CS2_TL_LAUNCH(true, false);
+        if (evap) CS2_TL_LAUNCH_I(true, true); else CS2_TL_LAUNCH_I(true, false);
     } else {
-        if (evap) CS2_TL_LAUNCH(false, true); else CS2_TL_LAUNCH(false, false);
+        if (evap) CS2_TL_LAUNCH_I(false, true); else CS2_TL_LAUNCH_I(false, false);
     }
+#undef CS2_TL_LAUNCH_I
 #undef CS2_TL_LAUNCH
-    note_kernel("cs2::tl_kernel");
+    note_kernel(inc ? "cs2::tl_kernel<inc>" : "cs2::tl_kernel");
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 template int launch_tl<double>(const Cloudsc2Params&, int, int, int64_t, const double* const*, const double* const*,
-                               const double*, double* const*, double* const*, double, hipStream_t);
+                               const double*, double* const*, double* const*, double, hipStream_t, double);
 template int launch_tl<float>(const Cloudsc2Params&, int, int, int64_t, const float* const*, const float* const*,
-                              const float*, float* const*, float* const*, double, hipStream_t);
+                              const float*, float* const*, float* const*, double, hipStream_t, double);
 
 }  // namespace cs2

@@ -15,7 +15,7 @@ def core(args):
     st = SymmetryTest(ctx["grid"], factor=0.01, kflag=1, lphylin=True, ldrain1d=False, yoethf_params=p["yoethf"],
                       yomcst_params=p["yomcst"], yrecldp_params=p["yrecldp"], yrephli_params=p["yrephli"],
                       yrncl_params=p["yrncl"], yrphnc_params=p["yrphnc"], enable_checks=cfg.sympl_enable_checks,
-                      gt4py_config=cfg.gt4py_config, ad_traj_fix=args.ad_traj_fix, graph=args.graph)
+                      gt4py_config=cfg.gt4py_config, ad_traj_fix=args.ad_traj_fix, graph=args.graph, fused=args.fused)
     ok = st(ctx["state"], ctx["dt"], enable_validation=cfg.enable_validation)   # warm-up + the validated call
     if args.tune_placement:
         # build extension: the ~80 fields of the test are re-placed in HBM where a whole run is fastest
@@ -40,6 +40,8 @@ def main(argv=None):
     add_common_options(ap)
     ap.add_argument("--ad-traj-fix", action="store_true",
                     help="use the AD kernel whose freezing tests match NL/TL (build extension, DESIGN.md 3.3)")
+    ap.add_argument("--fused", action="store_true",
+                    help="timed call: state_increment fused into cloudsc2_tl (build extension cloudsc2_tl_incremented)")
     ap.add_argument("--graph", action="store_true",
                     help="capture the timed call (saturation, state_increment, cloudsc2_tl, cloudsc2_ad) in a HIP graph and "
                          "replay it (one host call per run)")

@@ -13,7 +13,11 @@ observable contract).  Differences, all on the measurement side:
     `fused_norms=True` additionally forms the ten sums of NL(x + f x_i) - NL(x) in that kernel's epilogue (stencil
     `cloudsc2_nl_taylor`: no perturbed outputs are stored, no separate difference / sum kernels run);
     `fused_all=True` evaluates ALL step sizes in ceil(n / 5) launches that share the loads of a level (stencil
-    `cloudsc2_nl_taylor_multi`): the ten perturbed runs become bound by arithmetic instead of re-streaming the state;
+    `cloudsc2_nl_taylor_multi`): the ten perturbed runs become bound by arithmetic instead of re-streaming the state -
+    and `state_increment` is fused into cloudsc2_tl and into that kernel (stencil `cloudsc2_tl_incremented`, `f_inc=`):
+    the increments f1 * state are formed in the kernels and never stored (`state_i` stays empty in this mode);
+  * `SymmetryTest(..., fused=True)`: the TIMED call (validation off) runs `cloudsc2_tl_incremented` instead of
+    state_increment + cloudsc2_tl; the validated call keeps the separate launches (its norm needs `state_i`);
   * `graph=True` (both harnesses) captures the run's kernel sequence once into a HIP graph and replays it: one host
     call per run instead of the Python + ctypes path of ~35 launches (the caller must pass the same state storages);
   * `SymmetryTest(..., ad_traj_fix=True)` selects the AD kernel variant whose freezing tests match
@@ -30,8 +34,8 @@ import torch
 
 from .framework.timing import timing
 from .reductions import column_dots, field_sums
-from .physics import (Cloudsc2AD, Cloudsc2NL, Cloudsc2NLPerturbed, Cloudsc2TL, PerturbedState, Saturation,
-                      StateIncrement)
+from .physics import (Cloudsc2AD, Cloudsc2NL, Cloudsc2NLPerturbed, Cloudsc2TL, Cloudsc2TLIncremented, PerturbedState,
+                      Saturation, StateIncrement)
 
 _TENDS = ("f_t", "f_q", "f_ql", "f_qi")
 _DIAGS = ("f_clc", "f_fhpsl", "f_fhpsn", "f_fplsl", "f_fplsn", "f_covptot")
@@ -121,8 +125,12 @@ class TaylorTest:
         self.saturation = Saturation(computational_grid, kflag, lphylin, yoethf_params, yomcst_params, **kw)
         self.cloudsc2_nl = Cloudsc2NL(computational_grid, lphylin, ldrain1d, yoethf_params, yomcst_params,
                                       yrecldp_params, yrephli_params, yrphnc_params, **kw)
-        self.cloudsc2_tl = Cloudsc2TL(computational_grid, lphylin, ldrain1d, yoethf_params, yomcst_params,
-                                      yrecldp_params, yrephli_params, yrncl, yrphnc_params, **kw)
+        if fused_all:
+            self.cloudsc2_tl = Cloudsc2TLIncremented(computational_grid, factor1, False, lphylin, ldrain1d, yoethf_params,
+                                                     yomcst_params, yrecldp_params, yrephli_params, yrncl, yrphnc_params, **kw)
+        else:
+            self.cloudsc2_tl = Cloudsc2TL(computational_grid, lphylin, ldrain1d, yoethf_params, yomcst_params,
+                                          yrecldp_params, yrephli_params, yrncl, yrphnc_params, **kw)
         self.state_increment = StateIncrement(computational_grid, factor1, **kw)
         if self.fused_norms:
             self.perturbed_states = [None] * len(self.f2s)
@@ -170,8 +178,9 @@ class TaylorTest:
             state.update(self.diags_sat)
             self.tends_nl, self.diags_nl = self.cloudsc2_nl(state, timestep, out_tendencies=self.tends_nl,
                                                             out_diagnostics=self.diags_nl)
-            self.state_i = self.state_increment(state, out=self.state_i)
-            state.update(self.state_i)
+            if not self.fused_all:       # fused_all: the increments f1 * state are formed inside the kernels that use them
+                self.state_i = self.state_increment(state, out=self.state_i)
+                state.update(self.state_i)
             self.tends_tl, self.diags_tl = self.cloudsc2_tl(state, timestep, out_tendencies=self.tends_tl,
                                                             out_diagnostics=self.diags_tl)
         with timing("norms"):
@@ -208,13 +217,14 @@ class TaylorTest:
             host = _allreduce(sums.clone() if self.graph else sums, "sum").cpu().numpy()
             return np.array([self._norm(f2, host[1 + i], host[0]) for i, f2 in enumerate(self.f2s)])
 
-    def _nl_fields(self, state):
+    def _nl_fields(self, state, increments: bool = True):
         from .stencils import NL_IN, NL_OUT
 
         kw = {}
         for n in NL_IN:
             kw["in_" + n] = state["f_" + n].data
-            kw["in_" + n + "_i"] = state["f_" + n + "_i"].data
+            if increments:
+                kw["in_" + n + "_i"] = state["f_" + n + "_i"].data
         for n in NL_OUT:   # unperturbed outputs: tendencies are published as f_q / f_qi / f_ql / f_t
             kw["ref_" + n] = (self.tends_nl["f_" + n[len("tnd_"):]] if n.startswith("tnd_") else self.diags_nl["f_" + n]).data
         any_f = state["f_ap"].data
@@ -248,10 +258,11 @@ class TaylorTest:
         """(number of step sizes, 10): the sums of every step size from ceil(n / 5) launches that share their loads."""
         from .stencils import NL_OUT, taylor_blocks
 
-        kw, nx, nz, device = self._nl_fields(state)
+        kw, nx, nz, device = self._nl_fields(state, increments=False)
         part = torch.empty((taylor_blocks(nx), len(self.f2s), len(NL_OUT)), dtype=torch.float64, device=device)
         cfg = self._gt4py_config
-        self._taylor(**kw, out_partials=part, fs=self.f2s, dt=float(timestep.total_seconds()), origin=(0, 0, 0),
+        self._taylor(**kw, out_partials=part, fs=self.f2s, f_inc=float(cfg.dtypes.float(self.f1)),
+                     dt=float(timestep.total_seconds()), origin=(0, 0, 0),
                      domain=(nx, 1, nz + 1), validate_args=cfg.validate_args, exec_info=cfg.exec_info)
         return part.sum(dim=0).index_select(1, self._out_index(names, device))
 
@@ -279,9 +290,11 @@ class TaylorTest:
 class SymmetryTest:
     def __init__(self, computational_grid, factor: float, kflag: int, lphylin: bool, ldrain1d: bool, yoethf_params,
                  yomcst_params, yrecldp_params, yrephli_params, yrncl_params, yrphnc_params, *,
-                 enable_checks: bool = True, gt4py_config, ad_traj_fix: bool = False, graph: bool = False) -> None:
+                 enable_checks: bool = True, gt4py_config, ad_traj_fix: bool = False, graph: bool = False,
+                 fused: bool = False) -> None:
         self.f = factor
         self.graph = graph
+        self.fused = fused
         self._graphed: Optional[_GraphedRun] = None
         kw = dict(enable_checks=enable_checks, gt4py_config=gt4py_config)
         self.gt4py_config = gt4py_config
@@ -292,6 +305,11 @@ class SymmetryTest:
                                       yrecldp_params, yrephli_params, yrncl_params, yrphnc_params,
                                       ad_traj_fix=ad_traj_fix, **kw)
         self.state_increment = StateIncrement(computational_grid, factor, ignore_supsat=True, **kw)
+        self.cloudsc2_tl_incremented = None
+        if fused:
+            self.cloudsc2_tl_incremented = Cloudsc2TLIncremented(
+                computational_grid, factor, True, lphylin, ldrain1d, yoethf_params, yomcst_params, yrecldp_params,
+                yrephli_params, yrncl_params, yrphnc_params, **kw)
         self.diags_sat: Dict[str, Any] = {}
         self.state_i: Dict[str, Any] = {}
         self.tends_tl: Dict[str, Any] = {}
@@ -335,10 +353,15 @@ class SymmetryTest:
         """saturation, state_increment, cloudsc2_tl, [norm1,] cloudsc2_ad (:135-151); returns norm1 when validating"""
         self.diags_sat = self.saturation(state, out=self.diags_sat)
         state.update(self.diags_sat)
-        self.state_i = self.state_increment(state, out=self.state_i)
-        state.update(self.state_i)
-        self.tends_tl, self.diags_tl = self.cloudsc2_tl(state, timestep, out_tendencies=self.tends_tl,
-                                                        out_diagnostics=self.diags_tl)
+        if self.fused and not enable_validation:
+            # timed call: the increments factor * state are formed inside the TL kernel (nothing else reads them here)
+            self.tends_tl, self.diags_tl = self.cloudsc2_tl_incremented(state, timestep, out_tendencies=self.tends_tl,
+                                                                        out_diagnostics=self.diags_tl)
+        else:
+            self.state_i = self.state_increment(state, out=self.state_i)
+            state.update(self.state_i)
+            self.tends_tl, self.diags_tl = self.cloudsc2_tl(state, timestep, out_tendencies=self.tends_tl,
+                                                            out_diagnostics=self.diags_tl)
         norm1 = self._norm1() if enable_validation else None
         for n in _TENDS:                                        # add_tendencies_to_state (:222-231)
             state["f_tnd_" + n[2:]] = self.tends_tl[n]

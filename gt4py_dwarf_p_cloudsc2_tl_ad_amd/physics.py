@@ -306,6 +306,42 @@ class Cloudsc2TL(ImplicitTendencyComponent):
                       domain=(g.nx, 1, g.nz + 1), **_stencil_common(self))
 
 
+class Cloudsc2TLIncremented(Cloudsc2TL):
+    """BUILD EXTENSION: `StateIncrement(factor, ignore_supsat)` + `Cloudsc2TL` as ONE launch (stencil
+    `cloudsc2_tl_incremented`): the state needs no `f_*_i` fields, the perturbations are factor * state, formed in the
+    kernel.  Outputs are those of the two components called one after the other (up to the compiler's fma contraction of
+    the shared level function: ulps)."""
+
+    def __init__(self, computational_grid, factor: float, ignore_supsat: bool, lphylin: bool, ldrain1d: bool,
+                 yoethf_params, yomcst_params, yrecldp_params, yrephli_params, yrncl_params, yrphnc_params, *,
+                 enable_checks: bool = True, gt4py_config) -> None:
+        ImplicitTendencyComponent.__init__(self, computational_grid, enable_checks=enable_checks, gt4py_config=gt4py_config)
+        ext = _externals(yoethf_params, yomcst_params, yrecldp_params, yrephli_params, yrncl_params, yrphnc_params,
+                         ICALL=0, LPHYLIN=lphylin, LDRAIN1D=ldrain1d, NLEV=computational_grid.nz,
+                         ZEPS1=1e-12, ZEPS2=1e-10, ZQMAX=0.5, ZSCAL=0.9, IGNORE_SUPSAT=ignore_supsat)
+        self.f = gt4py_config.dtypes.float(factor)
+        self.cloudsc2 = self.compile_stencil("cloudsc2_tl_incremented", ext)
+
+    @cached_property
+    def input_grid_properties(self):
+        props = {"f_eta": {"grid_dims": (K,), "units": ""}}
+        for n in NL_IN:
+            props["f_" + n] = _prop(n)
+        return props
+
+    def array_call(self, state, timestep: timedelta, out_tendencies, out_diagnostics, overwrite_tendencies) -> None:
+        g = self.computational_grid
+        kw = {"in_" + n: state["f_" + n] for n in NL_IN}
+        for n in _DIAG_OUT:
+            kw["out_" + n] = out_diagnostics["f_" + n]
+            kw["out_" + n + "_i"] = out_diagnostics["f_" + n + "_i"]
+        for n in _TEND_OUT:
+            kw["out_" + n] = out_tendencies[_tend_name(n)]
+            kw["out_" + n + "_i"] = out_tendencies[_tend_name(n) + "_i"]
+        self.cloudsc2(**kw, in_eta=state["f_eta"], f=self.f, dt=self.gt4py_config.dtypes.float(timestep.total_seconds()),
+                      domain=(g.nx, 1, g.nz + 1), **_stencil_common(self))
+
+
 class Cloudsc2AD(ImplicitTendencyComponent):
     """State in: the 16 trajectory fields + the adjoint forcings `f_{clc,...}_i`, `f_tnd_{t,q,ql,qi}_i`
     (adjoint/microphysics.py:91-121).  Out: NL tendencies/diagnostics + `f_cml_{t,q,ql,qi}_i` (tendency

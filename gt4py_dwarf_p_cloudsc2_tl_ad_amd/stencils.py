@@ -297,7 +297,9 @@ class Cloudsc2NLTaylorMultiStencil(HipStencil):
     """BUILD EXTENSION `cloudsc2_nl_taylor_multi`: the Taylor test's perturbed NL runs for ALL step sizes (C ABI
     `cloudsc2_nl_taylor_multi_*`: up to 5 step sizes share one pass over the 42 words of a level).  Fields as
     `cloudsc2_nl_taylor`; `fs`: the step sizes; `out_partials`: contiguous float64 tensor of shape
-    (taylor_blocks(nx), len(fs), 10) receiving, per workgroup and step size, sum(NL(in + f in_i) - ref) in NL_OUT order."""
+    (taylor_blocks(nx), len(fs), 10) receiving, per workgroup and step size, sum(NL(in + f in_i) - ref) in NL_OUT order.
+    With `f_inc=<factor>` instead of the 16 `in_*_i` fields, `state_increment` is fused in as well: the increments are formed
+    in the kernel as f_inc * in (external IGNORE_SUPSAT zeroes the supsat increment)."""
 
     name = "cloudsc2_nl_taylor_multi"
 
@@ -306,11 +308,12 @@ class Cloudsc2NLTaylorMultiStencil(HipStencil):
             raise TypeError(f"{self.name}: missing argument 'fs' / 'out_partials'")
         self._fs = [float(x) for x in kwargs.pop("fs")]
         self._partials = kwargs.pop("out_partials")
+        self._f_inc = kwargs.pop("f_inc", None)
         super().__call__(**kwargs)
 
     def _field_names(self):
-        return (tuple("in_" + n for n in NL_IN) + tuple("in_" + n + "_i" for n in NL_IN)
-                + tuple("ref_" + n for n in NL_OUT))
+        incs = () if getattr(self, "_f_inc", None) is not None else tuple("in_" + n + "_i" for n in NL_IN)
+        return tuple("in_" + n for n in NL_IN) + incs + tuple("ref_" + n for n in NL_OUT)
 
     def _launch(self, fields, eta, scalar, nx, nz, ls, sfx, stream):
         if eta is None:
@@ -321,9 +324,11 @@ class Cloudsc2NLTaylorMultiStencil(HipStencil):
                 or part.device != fields["in_ap"].device or part.numel() < need):
             raise ValueError(f"{self.name}: out_partials must be a contiguous float64 device tensor with >= {need} elements")
         pf = (ctypes.c_double * max(nf, 1))(*self._fs)
+        fused_inc = self._f_inc is not None
         return self._fn("nl_taylor_multi", sfx)(
             ctypes.byref(self.params), nx, nz, ls, _ptrs(fields, ["in_" + n for n in NL_IN]),
-            _ptrs(fields, ["in_" + n + "_i" for n in NL_IN]), nf, pf, eta.data_ptr(),
+            None if fused_inc else _ptrs(fields, ["in_" + n + "_i" for n in NL_IN]),
+            float(self._f_inc) if fused_inc else 0.0, nf, pf, eta.data_ptr(),
             _ptrs(fields, ["ref_" + n for n in NL_OUT]), part.data_ptr(), scalar, stream)
 
 
@@ -349,6 +354,33 @@ class Cloudsc2TLStencil(HipStencil):
             ctypes.byref(self.params), nx, nz, ls,
             _ptrs(fields, ["in_" + n for n in NL_IN]), _ptrs(fields, ["in_" + n + "_i" for n in NL_IN]),
             eta.data_ptr(),
+            _ptrs(fields, ["out_" + n for n in NL_OUT]), _ptrs(fields, ["out_" + n + "_i" for n in NL_OUT]),
+            scalar, stream)
+
+
+class Cloudsc2TLIncrementedStencil(HipStencil):
+    """BUILD EXTENSION `cloudsc2_tl_incremented`: `state_increment` + `cloudsc2_tl` in one launch (C ABI
+    `cloudsc2_tl_incremented_*`): the perturbations are formed in the kernel as f * in_X (external IGNORE_SUPSAT: the
+    supsat perturbation is 0).  Arguments of `cloudsc2_tl` minus the 16 `in_*_i` fields, plus the scalar `f`."""
+
+    name = "cloudsc2_tl_incremented"
+
+    def __call__(self, **kwargs: Any) -> None:
+        if "f" not in kwargs:
+            raise TypeError(f"{self.name}: missing scalar argument 'f'")
+        self._f = float(kwargs.pop("f"))
+        super().__call__(**kwargs)
+
+    def _field_names(self):
+        return (tuple("in_" + n for n in NL_IN) + tuple("out_" + n for n in NL_OUT)
+                + tuple("out_" + n + "_i" for n in NL_OUT))
+
+    def _launch(self, fields, eta, scalar, nx, nz, ls, sfx, stream):
+        if eta is None:
+            raise TypeError(f"{self.name}: missing field argument 'in_eta'")
+        self._set_nlev(nz)
+        return self._fn("tl_incremented", sfx)(
+            ctypes.byref(self.params), nx, nz, ls, _ptrs(fields, ["in_" + n for n in NL_IN]), self._f, eta.data_ptr(),
             _ptrs(fields, ["out_" + n for n in NL_OUT]), _ptrs(fields, ["out_" + n + "_i" for n in NL_OUT]),
             scalar, stream)
 
@@ -431,6 +463,7 @@ STENCILS: Dict[str, type] = {
     "cloudsc2_nl_taylor": Cloudsc2NLTaylorStencil,           # build extension (fused + reduction)
     "cloudsc2_nl_taylor_multi": Cloudsc2NLTaylorMultiStencil,   # build extension (all step sizes, fused + reduction)
     "cloudsc2_tl": Cloudsc2TLStencil,
+    "cloudsc2_tl_incremented": Cloudsc2TLIncrementedStencil,    # build extension (state_increment fused in)
     "cloudsc2_ad": Cloudsc2ADStencil,
     "saturation": SaturationStencil,
     "state_increment": StateIncrementStencil,

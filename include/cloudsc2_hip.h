@@ -128,17 +128,19 @@ int32_t cloudsc2_nl_taylor_f32(const Cloudsc2Params* p, int32_t nx, int32_t nz, 
  * Replaces the whole loop of TaylorTest.run (tangent_linear/validation.py:162-176: perturbed_state, cloudsc2_nl, get_norm
  * per step size): a lane loads the 16 state + 16 increment + 10 reference words of a level once and evaluates the level
  * for up to 5 step sizes on them (internally ceil(nf / 5) launches), so the perturbed runs are bound by arithmetic instead
- * of re-streaming 42 words per level, column and step size.  `pf`: HOST array of the nf step sizes; `partials`: DEVICE
+ * of re-streaming 42 words per level, column and step size.  `in_i` may be NULL: the increments are then formed in the
+ * kernel as T(inc_f) * in (state_increment fused in, state_increment.py:61-80; p->IGNORE_SUPSAT zeroes the supsat
+ * increment), otherwise inc_f is ignored.  `pf`: HOST array of the nf step sizes; `partials`: DEVICE
  * array of cloudsc2_nl_taylor_blocks(nx) * nf * NL_NUM_OUT doubles, partials[(b * nf + j) * NL_NUM_OUT + f] = sum over
  * workgroup b's columns and all levels of (NL(in + pf[j] in_i) - ref_out)[f]; the caller adds the blocks. */
 int32_t cloudsc2_nl_taylor_multi_f64(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t lev_stride,
-                                     const double* const* in, const double* const* in_i, int32_t nf, const double* pf,
-                                     const double* eta, const double* const* ref_out, double* partials, double dt,
-                                     void* stream);
+                                     const double* const* in, const double* const* in_i, double inc_f, int32_t nf,
+                                     const double* pf, const double* eta, const double* const* ref_out, double* partials,
+                                     double dt, void* stream);
 int32_t cloudsc2_nl_taylor_multi_f32(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t lev_stride,
-                                     const float* const* in, const float* const* in_i, int32_t nf, const double* pf,
-                                     const float* eta, const float* const* ref_out, double* partials, double dt,
-                                     void* stream);
+                                     const float* const* in, const float* const* in_i, double inc_f, int32_t nf,
+                                     const double* pf, const float* eta, const float* const* ref_out, double* partials,
+                                     double dt, void* stream);
 
 /* ---- validation-norm reductions (BUILD EXTENSIONS; the reference reduces on the host with NumPy).
  * field_sums : per field f < nfields (<= 16), sum over nlev levels and nx columns of a[f] - b[f] (b == NULL: of a[f]);
@@ -191,6 +193,19 @@ int32_t cloudsc2_tl_f64(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t
 int32_t cloudsc2_tl_f32(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t lev_stride,
                         const float* const* in, const float* const* in_i, const float* eta,
                         float* const* out, float* const* out_i, double dt, void* stream);
+
+/* ---- cloudsc2_tl with state_increment fused in (BUILD EXTENSION).  The harnesses call state_increment and cloudsc2_tl back
+ * to back on the same state (tangent_linear/validation.py:159-164, adjoint/validation.py:138-143); here the perturbation
+ * fields are not read but formed in the kernel as in_i[f] = T(f) * in[f] (state_increment.py:61-80; with
+ * p->IGNORE_SUPSAT the supsat perturbation is 0, :77-80): 16 input streams instead of 32 and no increment launch.  The
+ * increments are the very products the increment kernel would store; the outputs equal those of the two separate calls up
+ * to the compiler's fma contraction of the shared level function (ulps). */
+int32_t cloudsc2_tl_incremented_f64(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t lev_stride,
+                                    const double* const* in, double f, const double* eta, double* const* out,
+                                    double* const* out_i, double dt, void* stream);
+int32_t cloudsc2_tl_incremented_f32(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t lev_stride,
+                                    const float* const* in, double f, const float* eta, float* const* out,
+                                    float* const* out_i, double dt, void* stream);
 
 /* ---- cloudsc2_ad : adjoint/_stencils/cloudsc2.py:24-996, called at adjoint/microphysics.py:159-238
  * `in`     : the 16 NL inputs (trajectory), NL_IN_* order;

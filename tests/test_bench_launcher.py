@@ -211,3 +211,36 @@ def test_two_ranks_with_real_kernels_reproduce_the_one_process_result(gpu):
     assert d2["outputs_finite"] is True and d2["value"] > 0
     for name, v1 in d1["validation_norm"].items():
         assert d2["validation_norm"][name] == pytest.approx(v1, rel=1e-12, abs=1e-300), name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config", [3, 4])
+def test_bench_lines_of_configs_3_and_4(gpu, config):
+    """`python bench.py --config 3 | 4`: BASELINE configs[2] / configs[3] as timed steps with the same JSON contract; the
+    record carries the reference's verdict string, a sequence-level `roofline` (sum of the algorithmic bytes of the step's
+    stencils / the step's time) and the opt-in variants, each with its own verdict."""
+    p = _run("--config", str(config), "--steps", "3", "--warmup", "1", "--cols", "8192")
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "verdict", "variants", "per_rank_ms"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["dtype"] == "f64" and d["value"] > 0 and d["vs_baseline"] is None
+    assert f"configs[{config - 1}]" in d["config"]["workload"] and d["config"]["columns_per_gpu"] == 8192
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["bytes_per_column"] == (939504 if config == 3 else 152760)             # SURVEY 8d, VERDICT r02 item 3
+    assert d["verdict"]["passed"] is True
+    if config == 3:
+        assert d["verdict"]["verdict"].startswith("The test passed with penalty") and len(d["verdict"]["norms"]) == 10
+        assert r["stencils_one_step"]["cloudsc2_nl"]["ncalls"] == 11 and r["stencils_one_step"]["perturbed_state"]["ncalls"] == 10
+        for name in ("graph", "fused", "fused_graph", "fused_all", "fused_all_graph"):
+            v = d["variants"][name]
+            assert "error" not in v and v["verdict"] == d["verdict"]["verdict"], (name, v)
+    else:
+        assert d["verdict"]["verdict"] == "The symmetry test passed. HOORAY!" and d["verdict"]["max_error_eps"] < 100
+        assert set(r["stencils_one_step"]) == {"saturation", "state_increment", "cloudsc2_tl", "cloudsc2_ad"}
+        for name in ("graph", "fused", "fused_graph"):
+            assert "error" not in d["variants"][name] and d["variants"][name]["passed"] is True, (name, d["variants"][name])

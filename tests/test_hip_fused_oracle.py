@@ -146,6 +146,61 @@ def test_taylor_kernels_match_the_oracle_and_each_other(gpu, dtype, sw):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("ignore_supsat", [False, True])
+def test_tl_with_fused_increment_equals_separate_calls_and_the_oracle(gpu, dtype, ignore_supsat):
+    """`cloudsc2_tl_incremented` (state_increment inside the TL kernel) against state_increment then cloudsc2_tl - 100x
+    tighter than the HIP-vs-oracle tolerance (the increments are the stored products exactly, `rounded_product`; the level
+    function is the same source, but hipcc's fma contraction depends on the kernel it is inlined into, as for the ring and
+    register paths of cloudsc2_nl) - and against the oracle's state_increment + cloudsc2_tl within the TL tolerance; the
+    multi-step Taylor kernel with `f_inc` against the same kernel fed with stored increments."""
+    import torch
+
+    from helpers import increments, run_oracle_tl
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd import storage
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.stencils import INC, compile_stencil, taylor_blocks
+
+    nx, nz, f1 = 600, 137, 0.01
+    ext = externals(NLEV=nz, IGNORE_SUPSAT=ignore_supsat, LREGCL=not ignore_supsat)
+    fields, eta, dt = nl_case(nx, dtype=dtype, seed=21)
+    want_nl, want_tl = run_oracle_tl(fields, increments(fields, f1, ignore_supsat), eta, dt, ext)
+    dev = to_device(fields, gpu)
+    com = dict(origin=(0, 0, 0), domain=(nx, 1, nz + 1), validate_args=True, exec_info=None)
+    eta_d = torch.as_tensor(eta, device=gpu)
+    Z = lambda: storage.zeros(nx, nz, dtype, gpu)  # noqa: E731
+    inc = {"out_" + n + "_i": Z() for n in INC}
+    compile_stencil("state_increment", ext)(**{"in_" + n: dev["in_" + n] for n in INC}, **inc, f=f1, **com)
+    dev_i = {"in_" + n + "_i": inc["out_" + n + "_i"] for n in INC}
+    sep = {**{"out_" + n: Z() for n in NL_OUT}, **{"out_" + n + "_i": Z() for n in NL_OUT}}
+    compile_stencil("cloudsc2_tl", ext)(**dev, **dev_i, **sep, in_eta=eta_d, dt=dt, **com)
+    fus = {**{"out_" + n: Z() for n in NL_OUT}, **{"out_" + n + "_i": Z() for n in NL_OUT}}
+    compile_stencil("cloudsc2_tl_incremented", ext)(**dev, **fus, in_eta=eta_d, dt=dt, f=f1, **com)
+    torch.cuda.synchronize()
+    for n in NL_OUT:
+        k = nlev_of(n, nz)
+        for sfx_, mul in (("", 1e-2), ("_i", 1.0)):      # perturbation fields: differences of nearly equal numbers
+            a_ = storage.klayout(fus["out_" + n + sfx_]).cpu().numpy()[:k]
+            b_ = storage.klayout(sep["out_" + n + sfx_]).cpu().numpy()[:k]
+            assert_close(f"tl-incremented vs separate out_{n}{sfx_}", a_, b_, dtype, rtol_mul=mul)
+    for n in NL_OUT:
+        k = nlev_of(n, nz)
+        assert_close(f"tl-incremented out_{n}", storage.klayout(fus["out_" + n]).cpu().numpy()[:k], want_nl[n][:k], dtype)
+        scale = float(np.abs(want_tl[n][:k]).max())
+        assert_close(f"tl-incremented out_{n}_i", storage.klayout(fus["out_" + n + "_i"]).cpu().numpy()[:k], want_tl[n][:k],
+                     dtype, scale=scale, rtol_mul=100.0)      # perturbation fields: the TL tests' allowance (helpers / DESIGN 4)
+    f2s = (1e-1, 1e-3, 1e-5)
+    refs = {"ref_" + n: sep["out_" + n] for n in NL_OUT}
+    multi = compile_stencil("cloudsc2_nl_taylor_multi", ext)
+    pa = torch.zeros((taylor_blocks(nx), len(f2s), len(NL_OUT)), dtype=torch.float64, device=gpu)
+    pb = torch.zeros_like(pa)
+    multi(**dev, **dev_i, **refs, out_partials=pa, fs=f2s, in_eta=eta_d, dt=dt, **com)
+    multi(**dev, **refs, out_partials=pb, fs=f2s, f_inc=f1, in_eta=eta_d, dt=dt, **com)
+    torch.cuda.synchronize()
+    sa, sb = pa.sum(dim=0).cpu().numpy(), pb.sum(dim=0).cpu().numpy()
+    mag = float(np.abs(sa).max())
+    assert mag > 0 and np.all(np.abs(sa - sb) <= (1e-11 if dtype == np.float64 else 1e-4) * mag), (sa, sb)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_reduction_kernels_match_torch(gpu, dtype):
     """`field_sums` / `column_dots` on aligned fields, on a column window of wider storages (lev_stride > nx) and on a
     size that is no multiple of the workgroup; 10 and 16 fields; with and without subtrahend"""
@@ -215,12 +270,18 @@ def test_symmetry_driver_graph_mode(gpu, capsys):
     from gt4py_dwarf_p_cloudsc2_tl_ad_amd.drivers import run_symmetry_test
 
     a = run_symmetry_test.main(["--backend", "hip", "--num-cols", "4096", "--num-runs", "3"])
-    b = run_symmetry_test.main(["--backend", "hip", "--num-cols", "4096", "--num-runs", "3", "--graph"])
-    assert a["passed"] and b["passed"] and a["detail"] == b["detail"]
-    for dct in ("tends_ad", "diags_ad", "tends_tl", "diags_tl"):
-        da, db = getattr(a["harness"], dct), getattr(b["harness"], dct)
-        assert set(da) == set(db) and len(da) >= 4
-        for k in da:
-            if hasattr(da[k], "data"):
-                assert torch.equal(da[k].data, db[k].data), (dct, k)
+    for extra in (["--graph"], ["--fused"], ["--fused", "--graph"]):
+        b = run_symmetry_test.main(["--backend", "hip", "--num-cols", "4096", "--num-runs", "3"] + extra)
+        assert a["passed"] and b["passed"]
+        assert a["detail"]["columns_passing"] == b["detail"]["columns_passing"] == 4096
+        for dct in ("tends_ad", "diags_ad", "tends_tl", "diags_tl"):
+            da, db = getattr(a["harness"], dct), getattr(b["harness"], dct)
+            assert set(da) == set(db) and len(da) >= 4
+            for k in da:
+                if hasattr(da[k], "data"):
+                    if "--fused" in extra:      # another kernel instantiation: same arithmetic, contraction may differ
+                        x, y = da[k].data.as_subclass(torch.Tensor), db[k].data.as_subclass(torch.Tensor)
+                        assert float((x - y).abs().max()) <= 1e-9 * max(float(y.abs().max()), 1e-300), (extra, dct, k)
+                    else:                        # graph replay of the same launches: bit for bit
+                        assert torch.equal(da[k].data, db[k].data), (extra, dct, k)
     assert "HOORAY" in capsys.readouterr().out

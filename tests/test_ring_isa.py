@@ -38,7 +38,13 @@ def test_nl_ring_loop_matches_the_hand_counted_waits(nl_asm):
 
 
 def test_nl_ring_guard_detects_a_dropped_store_and_a_foreign_wait(nl_asm):
-    i = nl_asm.index("global_store_dwordx2", nl_asm.index("nl_ring_kernelId"))
+    import re
+
+    k0 = nl_asm.index("nl_ring_kernelId")
+    # the first hand-written ring wait of that kernel (a vmcnt wait fused with the slot's ds_reads) ...
+    w = re.compile(r"s_waitcnt vmcnt\(\d+\)\n\s*ds_read_b64").search(nl_asm, k0).start()
+    # ... and the last store before it in the listing: one of the level's ten stores (the loop is rotated: stores on top)
+    i = nl_asm.rindex("global_store_dwordx2", k0, w)
     j = nl_asm.rindex("\n", 0, i) + 1
     with pytest.raises(AssertionError):
         isa.check_nl_ring(nl_asm[:j] + "\ts_nop 0 ; " + nl_asm[j:].lstrip())           # one store of a level gone

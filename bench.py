@@ -266,9 +266,10 @@ class _StdoutToStderr:
 # ------------------------------------------------------------------------------------------------ PMC traffic
 _PMC_FILES = (
     # (columns, precision) -> summaries of the separate FETCH_SIZE / WRITE_SIZE passes, newest round first
-    ((65536, "double"), ("profiles/r02/nl_fp64_65536_pmc.json", "profiles/r02/all_kernels_fp64_65536_pmc.json",
+    ((65536, "double"), ("profiles/r03/nl_fp64_65536_pmc.json", "profiles/r03/all_kernels_fp64_65536_pmc.json",
+                         "profiles/r02/nl_fp64_65536_pmc.json", "profiles/r02/all_kernels_fp64_65536_pmc.json",
                          "profiles/r01/nl_fp64_65536_pmc.json", "profiles/r01/all_kernels_fp64_65536_pmc.json")),
-    ((524288, "single"), ("profiles/r02/all_kernels_fp32_524288_pmc.json",)),
+    ((524288, "single"), ("profiles/r03/all_kernels_fp32_524288_pmc.json", "profiles/r02/all_kernels_fp32_524288_pmc.json")),
 )
 
 

@@ -30,7 +30,7 @@ EXPORTED_SYMBOLS = (
     "cloudsc2_nl_taylor_blocks", "cloudsc2_nl_taylor_f64", "cloudsc2_nl_taylor_f32",
     "cloudsc2_nl_taylor_multi_f64", "cloudsc2_nl_taylor_multi_f32",
     "cloudsc2_field_sums_blocks", "cloudsc2_field_sums_f64", "cloudsc2_field_sums_f32",
-    "cloudsc2_column_dots_f64", "cloudsc2_column_dots_f32",
+    "cloudsc2_column_dots_chunks", "cloudsc2_column_dots_f64", "cloudsc2_column_dots_f32",
     "cloudsc2_tl_f64", "cloudsc2_tl_f32",
     "cloudsc2_tl_incremented_f64", "cloudsc2_tl_incremented_f32",
     "cloudsc2_ad_f64", "cloudsc2_ad_f32",
@@ -62,6 +62,8 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.cloudsc2_nl_taylor_blocks.argtypes = [c_int32]
     lib.cloudsc2_field_sums_blocks.restype = c_int32
     lib.cloudsc2_field_sums_blocks.argtypes = [c_int32, c_int32]
+    lib.cloudsc2_column_dots_chunks.restype = c_int32
+    lib.cloudsc2_column_dots_chunks.argtypes = [c_int32]
     for sfx, real in (("f64", c_double), ("f32", c_float)):
         del real  # device pointers travel as integers (void*), never dereferenced on the host
         parr = POINTER(c_void_p)

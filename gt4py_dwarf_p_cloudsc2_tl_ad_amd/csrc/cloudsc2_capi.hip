@@ -14,6 +14,7 @@ template <typename T>
 int launch_nl_taylor_multi(const Cloudsc2Params&, int, int, int64_t, const T* const*, const T* const*, int, const double*,
                            const T*, const T* const*, double*, double, hipStream_t, double);
 int field_sums_blocks(int, int);
+int column_dots_chunks(int);
 template <typename T>
 int launch_field_sums(int, int, int64_t, int, const T* const*, const T* const*, double*, hipStream_t);
 template <typename T>
@@ -306,6 +307,7 @@ int32_t cloudsc2_nl_taylor_multi_f32(const Cloudsc2Params* p, int32_t nx, int32_
                                        partials, dt, stream);
 }
 int32_t cloudsc2_field_sums_blocks(int32_t nx, int32_t nlev) { return cs2::field_sums_blocks(nx, nlev); }
+int32_t cloudsc2_column_dots_chunks(int32_t nlev) { return cs2::column_dots_chunks(nlev); }
 int32_t cloudsc2_field_sums_f64(int32_t nx, int32_t nlev, int64_t ls, int32_t nf, const double* const* a,
                                 const double* const* b, double* partials, void* stream) {
     return sums_impl<double>("cloudsc2_field_sums_f64", nx, nlev, ls, nf, a, b, partials, stream);

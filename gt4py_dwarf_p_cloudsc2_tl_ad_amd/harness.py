@@ -46,6 +46,8 @@ class _GraphedRun:
     returns the same output tensors.  The stencils launch on torch's current stream, so `torch.cuda.graph` records them."""
 
     def __init__(self, enqueue, gt4py_config) -> None:
+        if not torch.cuda.is_available():
+            raise RuntimeError("graph=True replays a HIP graph: it needs the hip backend on a GPU")
         saved = gt4py_config.exec_info
         gt4py_config.exec_info = None              # per-stencil HIP events cannot be recorded inside a capture
         try:

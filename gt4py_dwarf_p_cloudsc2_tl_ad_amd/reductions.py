@@ -76,7 +76,7 @@ def column_dots(a: Sequence[torch.Tensor], b: Optional[Sequence[torch.Tensor]] =
             out = s if out is None else out + s
         return out
     lib = _lib.load()
-    out = torch.empty((nx,), dtype=torch.float64, device=first.device)
+    out = torch.empty((int(lib.cloudsc2_column_dots_chunks(nlev)), nx), dtype=torch.float64, device=first.device)
     fn = getattr(lib, "cloudsc2_column_dots_" + _SFX[first.dtype])
     stream = int(torch.cuda.current_stream(first.device).cuda_stream)
     with torch.cuda.device(first.device):
@@ -85,4 +85,4 @@ def column_dots(a: Sequence[torch.Tensor], b: Optional[Sequence[torch.Tensor]] =
             rc = fn(nx, nlev, ls, len(pa), _lib.ptr_array([x.data_ptr() for x in pa]),
                     _lib.ptr_array([x.data_ptr() for x in pb]), out.data_ptr(), 1 if i else 0, stream)
             _lib.check(rc, "column_dots")
-    return out
+    return out.sum(dim=0)          # level-chunk partials, fixed order

@@ -147,9 +147,12 @@ int32_t cloudsc2_nl_taylor_multi_f32(const Cloudsc2Params* p, int32_t nx, int32_
  *              the difference is formed in the field type, accumulated in double - TaylorTest.get_field_norm's
  *              np.sum(field_nl_p - field_nl) and np.sum(field_tl) (tangent_linear/validation.py:250-261).  Workgroup w
  *              writes partials[w * nfields + f]; `partials` holds cloudsc2_field_sums_blocks(nx, nlev) * nfields doubles.
- * column_dots: out[c] (+)= sum over pairs p < npairs (<= 16) and nlev levels of a[p][k][c] * b[p][k][c] in double -
- *              SymmetryTest.get_norm1 / get_norm2 (adjoint/validation.py:167-215); `accumulate` != 0 adds to out. */
+ * column_dots: per column c, the sum over pairs p < npairs (<= 16) and nlev levels of a[p][k][c] * b[p][k][c] in double -
+ *              SymmetryTest.get_norm1 / get_norm2 (adjoint/validation.py:167-215) - delivered as level-chunk partials:
+ *              out[j * nx + c] (+)= the sum over chunk j's levels, j < cloudsc2_column_dots_chunks(nlev); the caller adds
+ *              the chunks.  `accumulate` != 0 adds to what `out` holds (for more than 16 pairs: a second call). */
 int32_t cloudsc2_field_sums_blocks(int32_t nx, int32_t nlev);
+int32_t cloudsc2_column_dots_chunks(int32_t nlev);
 int32_t cloudsc2_field_sums_f64(int32_t nx, int32_t nlev, int64_t lev_stride, int32_t nfields, const double* const* a,
                                 const double* const* b, double* partials, void* stream);
 int32_t cloudsc2_field_sums_f32(int32_t nx, int32_t nlev, int64_t lev_stride, int32_t nfields, const float* const* a,

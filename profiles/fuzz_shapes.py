@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Shape / switch fuzz of the HIP kernels against the NumPy oracle (dev tool, run on the GPU box):
 random nx (whole waves, ragged, tiny), random nz (3 .. 80: very short columns, windows longer than the levels above
-them, no window at all), both precisions, random externals switches; NL, TL and AD each time.
+them, no window at all), both precisions, random externals switches; NL, TL and AD each time, plus the round-3 build
+extensions on every case: the multi-step Taylor kernel against the one-step kernel (same sums) and `cloudsc2_tl_incremented`
+against state_increment + cloudsc2_tl.
    python profiles/fuzz_shapes.py [cases] [seed]"""
 import os
 import sys
@@ -60,6 +62,32 @@ def main():
             scale = max(float(np.abs(want[n]).max()), float(np.abs(want[partner]).max()), floor[n])
             assert_close(f"NL {n} {tag}", got[n][:k], want[n][:k], dtype, scale=scale)
         evap = bool(sw.get("LEVAPLS2") or sw.get("LDRAIN1D"))
+        # build extensions on the same shape: the Taylor sums of three step sizes from ONE multi-step launch against three
+        # launches of the one-step kernel (same level function, same reduction order), increments fused and stored
+        from gt4py_dwarf_p_cloudsc2_tl_ad_amd import storage
+        from gt4py_dwarf_p_cloudsc2_tl_ad_amd.stencils import compile_stencil, taylor_blocks
+        from helpers import to_device
+
+        dev, dev_i = to_device(fields, gpu), to_device(increments(fields, 0.01), gpu)
+        refs = {"ref_" + n: storage.from_klayout(got[n], dtype, gpu) for n in NL_OUT}
+        com = dict(in_eta=torch.as_tensor(eta, device=gpu), dt=dt, origin=(0, 0, 0), domain=(nx, 1, nz + 1),
+                   validate_args=True, exec_info=None)
+        f2s = (1e-1, 1e-3, 1e-6)
+        nb = taylor_blocks(nx)
+        p1 = torch.zeros((len(f2s), nb, len(NL_OUT)), dtype=torch.float64, device=gpu)
+        pm = torch.full((nb, len(f2s), len(NL_OUT)), float("nan"), dtype=torch.float64, device=gpu)
+        pi = torch.full((nb, len(f2s), len(NL_OUT)), float("nan"), dtype=torch.float64, device=gpu)
+        one = compile_stencil("cloudsc2_nl_taylor", ext)
+        for j, f2 in enumerate(f2s):
+            one(**dev, **dev_i, **refs, out_partials=p1[j], f=f2, **com)
+        multi = compile_stencil("cloudsc2_nl_taylor_multi", ext)
+        multi(**dev, **dev_i, **refs, out_partials=pm, fs=f2s, **com)
+        multi(**dev, **refs, out_partials=pi, fs=f2s, f_inc=0.01, **com)
+        torch.cuda.synchronize()
+        s1, sm, si = p1.sum(dim=1).cpu().numpy(), pm.sum(dim=0).cpu().numpy(), pi.sum(dim=0).cpu().numpy()
+        mag = np.array([float(np.abs(got[n]).sum()) for n in NL_OUT]) + 1e-300
+        tolm = 1e-11 if dtype == np.float64 else 1e-4
+        assert np.all(np.abs(sm - s1) <= tolm * mag) and np.all(np.abs(si - s1) <= tolm * mag), f"Taylor multi {tag}: {sm} vs {s1}"
         if dtype == np.float64 and not evap:
             # TL with general increments, AD with general forcings, every column on its own scale.  (The evaporation
             # block's perturbations are ill-conditioned by construction - the reference's dt**2 quirk, DESIGN 3.3 - and on
@@ -76,6 +104,15 @@ def main():
                 sc = max(float(np.abs(wt[n]).max()), float(np.abs(wt[partner]).max()), floor[n])
                 assert_close(f"TL {n} {tag}", gt[n][:k], wt[n][:k], dtype, scale=sc)
                 by_column(f"TL {n}_i {tag}", gti[n][:k], wti[n][:k], 1e-6)
+            # state_increment fused into cloudsc2_tl: against the oracle's state_increment + cloudsc2_tl
+            wt2, wti2 = run_oracle_tl(fields, increments(fields, 0.01), eta, tdt, ext)
+            fus = {**{"out_" + n: storage.zeros(nx, nz, dtype, gpu) for n in NL_OUT},
+                   **{"out_" + n + "_i": storage.zeros(nx, nz, dtype, gpu) for n in NL_OUT}}
+            compile_stencil("cloudsc2_tl_incremented", ext)(**dev, **fus, f=0.01, **com)
+            torch.cuda.synchronize()
+            for n in NL_OUT:
+                k = nlev_of(n, nz)
+                by_column(f"TL-incremented {n}_i {tag}", storage.klayout(fus["out_" + n + "_i"]).cpu().numpy()[:k], wti2[n][:k], 1e-6)
             forcing = {}
             for n in NL_OUT:
                 sc = max(float(np.abs(wt[n]).max()), 1e-30) if n != "covptot" else 1.0

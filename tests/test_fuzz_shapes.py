@@ -18,4 +18,8 @@ def test_fuzz_slice_agrees_with_the_oracle(gpu, seed, monkeypatch, capsys):
     spec.loader.exec_module(mod)
     monkeypatch.setattr(sys, "argv", ["fuzz_shapes.py", "40", str(seed)])
     mod.main()
-    assert "fuzz: 40 cases agree with the oracle" in capsys.readouterr().out
+    out = capsys.readouterr().out
+    assert "fuzz: 40 cases agree with the oracle" in out
+    import re
+
+    assert int(re.search(r"\((\d+) TL-incremented fields held to the oracle directly\)", out).group(1)) >= 50

@@ -429,3 +429,42 @@ def test_validation_drivers_in_single_precision_at_65536_columns(gpu, capsys):
     assert ("The symmetry test passed. HOORAY!" in out) == bool(s["passed"])
     assert np.isfinite(s["detail"]["max_error_eps"]) and s["detail"]["columns"] == 65536
     assert s["detail"]["columns_passing"] / s["detail"]["columns"] > 0.95, s["detail"]
+
+
+@pytest.mark.gpu
+def test_timing_brackets_do_not_drain_the_pipeline(gpu):
+    """`timing()` records a HIP event pair instead of synchronising on both sides (the reference opens 22 brackets per
+    Taylor run): the interval it reports for asynchronous GPU work is the device time of that work, a bracket around host-side
+    work reports host time, nested / repeated labels add up, and nothing synchronises until the time is asked for."""
+    import time
+
+    import torch
+
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.framework.timing import Timer, timing
+
+    x = torch.zeros(1 << 26, dtype=torch.float64, device=gpu)          # 512 MB: a fill takes ~0.1-0.2 ms
+    Timer.reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        with timing("fill"):
+            for _ in range(5):
+                x.add_(1.0)
+    enqueue_s = time.perf_counter() - t0
+    pending = len(Timer._pending)
+    ms = Timer.get_time("fill")                                          # resolves: ONE synchronisation
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(100):
+        x.add_(1.0)
+    b.record()
+    torch.cuda.synchronize()
+    want = a.elapsed_time(b)
+    assert pending == 20 and not Timer._pending
+    assert 0.7 * want < ms < 1.5 * want, (ms, want)                      # the device time of the 100 fills
+    assert enqueue_s * 1e3 < ms                                          # the host ran ahead: no drain per bracket
+    with timing("host"):
+        time.sleep(0.05)
+    assert 45.0 < Timer.get_time("host") < 80.0                          # host-side work: the host clock
+    Timer.reset()
+    assert Timer.get_time("fill") == 0.0

@@ -35,6 +35,14 @@ def test_run_nonlinear_unmodified(tmp_path):
     assert "cloudsc2_nl" in (tmp_path / "stencils.csv").read_text()
 
 
+def test_config1_run_nonlinear_unmodified_at_16384_columns():
+    """BASELINE configs[0] at its stated size: the UNMODIFIED reference driver, 16 384 columns x 137 levels fp64 on the host
+    CPU (plumbing, no GPU), with its golden comparison step - the stand-in dataset tiled to 16 384 columns."""
+    out = _run("run_nonlinear.py", "--num-cols", "16384", "--num-runs", "1")
+    assert "Performance: 16384 columns, 1 runs" in out and "== Validation:" in out
+    assert "f_covptot   : max abs err 0.000e+00" in out and "f_qv         (as f_q)" in out
+
+
 def test_run_taylor_test_unmodified():
     out = _run("run_taylor_test.py", "--num-cols", "64", "--num-runs", "1")
     assert ">>> Taylor test: Start" in out and "<<< Taylor test: End" in out

@@ -28,11 +28,13 @@ def core(args):
         finally:
             st.graph = graph
         report_placement(ctx["placement"], "run")
-    runtimes = []
-    for i in range(cfg.num_runs):
-        with timing(f"run_{i}") as timer:
+    from ..framework.timing import Timer
+
+    Timer.reset()
+    for i in range(cfg.num_runs):      # one HIP-event bracket per run (run_symmetry_test.py:94-98); read after the loop
+        with timing(f"run_{i}"):
             st(ctx["state"], ctx["dt"], enable_validation=False)
-        runtimes.append(timer.get_time(f"run_{i}", units="ms"))
+    runtimes = [Timer.get_time(f"run_{i}", units="ms") for i in range(cfg.num_runs)]
     mean = statistics.fmean(runtimes)
     std = statistics.stdev(runtimes) if len(runtimes) > 1 else 0.0
     print(f"\nThe test completed in {mean:.3f} ± {std:.3f} ms.")

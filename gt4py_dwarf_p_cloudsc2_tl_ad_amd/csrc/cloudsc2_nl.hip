@@ -1016,6 +1016,39 @@ __device__ __forceinline__ void nl_load_refs(const CPtrs<T, NL_NUM_OUT>& ref, ui
     }
 }
 
+// The running sums of one step size: ten fp64 words in LDS, field f of this lane at `addr + f * kColBlock * 8`.  Left to
+// hipcc, every `sum += d` became ds_read / s_waitcnt lgkmcnt(0) / add / ds_write back to back - fifty exposed LDS round
+// trips per level, a third of the kernel's time at one wave per SIMD (PMC: VALU-active 69 %).  So the ten reads of a step
+// size are ISSUED here, before its level is evaluated, and only waited for (acc_wait) when the differences are ready: the
+// latency hides behind ~570 VALU instructions.  The asm is a compiler barrier for memory operations (the previous level's
+// ds_write of the same words must stay ahead of it); lgkmcnt(0) also covers whatever LDS / scalar loads hipcc has in flight.
+#ifndef CS2_NL_MULTI_PREISSUE
+#define CS2_NL_MULTI_PREISSUE 0   // measured: 2.34 vs 2.28 ms for the ten step sizes - the LDS round trips are not what the kernel waits for
+#endif
+__device__ __forceinline__ void acc_issue(uint32_t addr, double (&v)[NL_NUM_OUT]) {
+    static_assert(NL_NUM_OUT == 10 && kColBlock * 8 == 2048, "offsets below are f * kColBlock * sizeof(double)");
+    asm volatile(
+        "ds_read_b64 %0, %10\n\t"
+        "ds_read_b64 %1, %10 offset:2048\n\t"
+        "ds_read_b64 %2, %10 offset:4096\n\t"
+        "ds_read_b64 %3, %10 offset:6144\n\t"
+        "ds_read_b64 %4, %10 offset:8192\n\t"
+        "ds_read_b64 %5, %10 offset:10240\n\t"
+        "ds_read_b64 %6, %10 offset:12288\n\t"
+        "ds_read_b64 %7, %10 offset:14336\n\t"
+        "ds_read_b64 %8, %10 offset:16384\n\t"
+        "ds_read_b64 %9, %10 offset:18432"
+        : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]), "=&v"(v[8]),
+          "=&v"(v[9])
+        : "v"(addr)
+        : "memory");
+}
+__device__ __forceinline__ void acc_wait(double (&v)[NL_NUM_OUT]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
+                   "+v"(v[9]));
+}
+
 template <typename T, bool EVAP, bool LIN, bool PINK, int NF, bool INC>
 __global__ void __launch_bounds__(kColBlock, 1)
 nl_taylor_multi_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, NL_NUM_IN> in,
@@ -1050,6 +1083,9 @@ nl_taylor_multi_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t 
     const uint32_t lsb = uint32_t(ls) * uint32_t(sizeof(T));
     const uint32_t colb = uint32_t(col) * uint32_t(sizeof(T));
 
+    // LDS byte address of this lane's first running sum (the low 32 bits of a generic pointer into LDS are its LDS offset)
+    const uint32_t acc_addr = uint32_t(reinterpret_cast<uintptr_t>(s_acc));
+    (void)acc_addr;
     T trpaus[NF];
     trpaus_prescan_multi<T, NF, INC>(in.p[NL_IN_T], in.p[NL_IN_TND_CML_T], in_i.p[NL_IN_T], in_i.p[NL_IN_TND_CML_T], lsb, colb,
                                      dt, s_eta, klo, khi, pf, finc, trpaus);
@@ -1075,52 +1111,68 @@ nl_taylor_multi_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t 
         }
     }
 
-    // register double buffer: level k+1's 42 words are requested before level k's NF evaluations
-    NLIn<T> bufa[2], bufb[INC ? 1 : 2];
-    T bufr[2][NL_NUM_OUT];
-    bufa[0] = nl_load<T, false>(in, lsb, colb);
-    if constexpr (!INC) bufb[0] = nl_load<T, false>(in_i, lsb, colb);
-    nl_load_refs<T>(ref, lsb, colb, bufr[0]);
-    bufa[1] = bufa[0];
-    if constexpr (!INC) bufb[1] = bufb[0];
-#pragma unroll
-    for (int f = 0; f < NL_NUM_OUT; ++f) bufr[1][f] = bufr[0][f];
+    // level k+1's 26-42 words are requested before level k's NF evaluations and handed over by register copies at the top of
+    // the next level (`cur = next`): the copy is the only consumer of the prefetched words, so they have a whole level of
+    // arithmetic (~5 us) to arrive.  (A two-way unrolled double buffer without copies - the shape nl_kernel uses - made
+    // hipcc consume ten of the 26 words 76 instructions after requesting them: VALU-active 69 %.)
+#ifndef CS2_NL_MULTI_COPYBUF
+#define CS2_NL_MULTI_COPYBUF 1
+#endif
+    NLIn<T> xa = nl_load<T, false>(in, lsb, colb), xb;
+    if constexpr (!INC) xb = nl_load<T, false>(in_i, lsb, colb);
+    T xr[NL_NUM_OUT];
+    nl_load_refs<T>(ref, lsb, colb, xr);
     uint32_t o = colb;
-    for (int k0 = 0; k0 < nz; k0 += 2) {
+    for (int k = 0; k < nz; ++k) {
+        NLIn<T> na = xa, nb = xb;
+        T nr[NL_NUM_OUT];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int k = k0 + s;
-            if (k < nz) {
-                if (k + 1 < nz) {
-                    bufa[s ^ 1] = nl_load<T, false>(in, lsb, o + lsb);
-                    if constexpr (!INC) bufb[s ^ 1] = nl_load<T, false>(in_i, lsb, o + lsb);
-                    nl_load_refs<T>(ref, lsb, o + lsb, bufr[s ^ 1]);
-                }
-                const T eta_k = s_eta[k], scalm_k = s_scalm[k];
-                NLIn<T> inc_k;
-                if constexpr (INC) inc_k = nl_increment<T>(bufa[s], finc, zero_supsat_i != 0);
-                const NLIn<T>& xi = INC ? inc_k : bufb[INC ? 0 : s];
+        for (int f = 0; f < NL_NUM_OUT; ++f) nr[f] = xr[f];
+        if (k + 1 < nz) {
+            na = nl_load<T, false>(in, lsb, o + lsb);
+            if constexpr (!INC) nb = nl_load<T, false>(in_i, lsb, o + lsb);
+            nl_load_refs<T>(ref, lsb, o + lsb, nr);
+        }
+        const T eta_k = s_eta[k], scalm_k = s_scalm[k];
+        NLIn<T> inc_k;
+        if constexpr (INC) inc_k = nl_increment<T>(xa, finc, zero_supsat_i != 0);
+        const NLIn<T>& xi = INC ? inc_k : xb;
 #pragma unroll
-                for (int j = 0; j < NF; ++j) {
-                    const NLIn<T> x = nl_perturb<T>(bufa[s], xi, pf.f[j]);
-                    const NLOut<T> r = nl_level<T, EVAP, LIN>(e, kc, xk, x, eta_k, scalm_k, crh[j], dt, aph_s[j], c[j]);
-                    if (live) {
-                        double* const a = s_acc + j * NL_NUM_OUT * kColBlock;
-                        a[NL_OUT_CLC * kColBlock] += double(r.clc - bufr[s][NL_OUT_CLC]);
-                        a[NL_OUT_COVPTOT * kColBlock] += double(r.covptot - bufr[s][NL_OUT_COVPTOT]);
-                        a[NL_OUT_TND_Q * kColBlock] += double(r.tnd_q - bufr[s][NL_OUT_TND_Q]);
-                        a[NL_OUT_TND_T * kColBlock] += double(r.tnd_t - bufr[s][NL_OUT_TND_T]);
-                        a[NL_OUT_TND_QL * kColBlock] += double(r.tnd_ql - bufr[s][NL_OUT_TND_QL]);
-                        a[NL_OUT_TND_QI * kColBlock] += double(r.tnd_qi - bufr[s][NL_OUT_TND_QI]);
-                        a[NL_OUT_FPLSL * kColBlock] += double(r.rfln - bufr[s][NL_OUT_FPLSL]);
-                        a[NL_OUT_FPLSN * kColBlock] += double(r.sfln - bufr[s][NL_OUT_FPLSN]);
-                        a[NL_OUT_FHPSL * kColBlock] += double(enthalpy_diff<T>(r.rfln, e.RLVTT, bufr[s][NL_OUT_FHPSL]));
-                        a[NL_OUT_FHPSN * kColBlock] += double(enthalpy_diff<T>(r.sfln, e.RLSTT, bufr[s][NL_OUT_FHPSN]));
-                    }
-                }
-                o += lsb;
+        for (int j = 0; j < NF; ++j) {
+            double* const a = s_acc + j * NL_NUM_OUT * kColBlock;
+            double sum[NL_NUM_OUT];
+#if CS2_NL_MULTI_PREISSUE
+            acc_issue(acc_addr + uint32_t(j * NL_NUM_OUT * kColBlock * sizeof(double)), sum);
+#endif
+            const NLIn<T> x = nl_perturb<T>(xa, xi, pf.f[j]);
+            const NLOut<T> r = nl_level<T, EVAP, LIN>(e, kc, xk, x, eta_k, scalm_k, crh[j], dt, aph_s[j], c[j]);
+            double d[NL_NUM_OUT];
+            d[NL_OUT_CLC] = double(r.clc - xr[NL_OUT_CLC]);
+            d[NL_OUT_COVPTOT] = double(r.covptot - xr[NL_OUT_COVPTOT]);
+            d[NL_OUT_TND_Q] = double(r.tnd_q - xr[NL_OUT_TND_Q]);
+            d[NL_OUT_TND_T] = double(r.tnd_t - xr[NL_OUT_TND_T]);
+            d[NL_OUT_TND_QL] = double(r.tnd_ql - xr[NL_OUT_TND_QL]);
+            d[NL_OUT_TND_QI] = double(r.tnd_qi - xr[NL_OUT_TND_QI]);
+            d[NL_OUT_FPLSL] = double(r.rfln - xr[NL_OUT_FPLSL]);
+            d[NL_OUT_FPLSN] = double(r.sfln - xr[NL_OUT_FPLSN]);
+            d[NL_OUT_FHPSL] = double(enthalpy_diff<T>(r.rfln, e.RLVTT, xr[NL_OUT_FHPSL]));
+            d[NL_OUT_FHPSN] = double(enthalpy_diff<T>(r.sfln, e.RLSTT, xr[NL_OUT_FHPSN]));
+#if CS2_NL_MULTI_PREISSUE
+            acc_wait(sum);
+#else
+#pragma unroll
+            for (int f = 0; f < NL_NUM_OUT; ++f) sum[f] = a[f * kColBlock];
+#endif
+            if (live) {
+#pragma unroll
+                for (int f = 0; f < NL_NUM_OUT; ++f) a[f * kColBlock] = sum[f] + d[f];
             }
         }
+        xa = na;
+        if constexpr (!INC) xb = nb;
+#pragma unroll
+        for (int f = 0; f < NL_NUM_OUT; ++f) xr[f] = nr[f];
+        o += lsb;
     }
     // workgroup reduction of the NF x 10 sums: wave shuffle, then one LDS hop
     __shared__ double s_red[kColBlock / 64][NF * NL_NUM_OUT];

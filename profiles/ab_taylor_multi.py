@@ -59,6 +59,11 @@ def main():
                                                              eta.data_ptr(), P(ref, NL_OUT), part.data_ptr(), 3600.0, stream)
         assert rc == 0, lib.cloudsc2_last_error()
 
+    def multi_inc(lib):
+        rc = getattr(lib, "cloudsc2_nl_taylor_multi_" + sfx)(ctypes.byref(p), nx, nz, nx, P(f, NL_IN), None, 0.01, 10, pf,
+                                                             eta.data_ptr(), P(ref, NL_OUT), part.data_ptr(), 3600.0, stream)
+        assert rc == 0, lib.cloudsc2_last_error()
+
     def single(lib):
         for f2 in f2s:
             rc = getattr(lib, "cloudsc2_nl_taylor_" + sfx)(ctypes.byref(p), nx, nz, nx, P(f, NL_IN), P(fi, NL_IN), f2,
@@ -75,10 +80,11 @@ def main():
     for name, v in sums.items():
         print(f"{name:>10s}: max |sum - first build's| / max|sum| = {np.abs(v - base).max() / np.abs(base).max():.2e}")
     times = {n: [] for n in libs}
+    times.update({n + "+inc": [] for n in libs})
     times["one-step x10"] = []
     for _ in range(rounds):
-        for name, lib in list(libs.items()) + [("one-step x10", first)]:
-            fn = single if name == "one-step x10" else multi
+        for name, lib in list(libs.items()) + [(n + "+inc", l) for n, l in libs.items()] + [("one-step x10", first)]:
+            fn = single if name == "one-step x10" else (multi_inc if name.endswith("+inc") else multi)
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             for _ in range(3):

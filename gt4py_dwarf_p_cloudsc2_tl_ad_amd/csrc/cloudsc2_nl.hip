@@ -26,9 +26,6 @@
 #ifndef CS2_NL_PINK
 #define CS2_NL_PINK 1   // pin the named physical constants in VGPRs (fp64 only)
 #endif
-#ifndef CS2_NL_PREFETCH
-#define CS2_NL_PREFETCH 1   // register path: levels in flight ahead of the one being computed (1 measured best: the
-#endif                      // access pattern, not latency, bounds the kernel - profiles/microbench_stream.hip)
 #ifndef CS2_NL_DIAG
 #define CS2_NL_DIAG 0   // diagnostics only (wrong results): 1 = memory traffic without the physics,
 #endif                  // 2 = physics without HBM traffic (inputs from 2 cached levels, no stores)
@@ -446,67 +443,58 @@ nl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
         stg(out.p[NL_OUT_FHPSN], colb, T(0.0));
     }
 
-    // Level sweep with a software prefetch ring of depth PD: while level k is computed, the inputs
-    // of levels k+1 .. k+PD are in flight (one wave per SIMD at 65 536 columns: HBM latency can only
-    // hide behind this wave's own work).
-    constexpr int PD = CS2_NL_PREFETCH;
-    NLIn<T> buf[PD + 1];
+    // Level sweep with ONE level of software prefetch: level k+1's words are requested before level k is computed and
+    // handed over by register copies at the end of the level (`xa = xn`, the shape of tl_kernel / ad_kernel), so the only
+    // consumer of a prefetched word is that copy, a whole level of arithmetic later.  r03: the earlier form - a rotating
+    // buffer `buf[PD + 1]` in a loop unrolled PD + 1 times, no copies - compiled to `s_waitcnt vmcnt(0)` right behind the
+    // loads of every second level (the compiled ISA shows it: 16 / 32 loads, then the wait 0 / 19 instructions later), i.e.
+    // every other level paid the full HBM latency.  Deeper register prefetch was measured in r01 (spills; 1 is best).
     constexpr bool PERT = FUSE == 2 || FUSE == 3;
-    NLIn<T> bufi[PERT ? PD + 1 : 1];
-#pragma unroll
-    for (int j = 0; j < PD; ++j) {
-        const uint32_t oj = colb + uint32_t(j < nz ? j : 0) * lsb;
-        buf[j] = nl_load<T, FUSE == 1>(in, lsb, oj, keepq != 0);
-        if constexpr (PERT) bufi[j] = nl_load<T, false>(in_i, lsb, oj);
-    }
-    buf[PD] = buf[0];
-    if constexpr (PERT) bufi[PD] = bufi[0];
+    NLIn<T> xa = nl_load<T, FUSE == 1>(in, lsb, colb, keepq != 0);
+    NLIn<T> xia;
+    if constexpr (PERT) xia = nl_load<T, false>(in_i, lsb, colb);
     double acc[FUSE == 3 ? NL_NUM_OUT : 1] = {};
     uint32_t o = colb;  // byte offset of (level k, column)
-    for (int k0 = 0; k0 < nz; k0 += PD + 1) {
+    for (int k = 0; k < nz; ++k) {
+        NLIn<T> xn = xa, xin = xia;
+        if (k + 1 < nz) {
+            xn = nl_load<T, FUSE == 1>(in, lsb, o + lsb, keepq != 0);
+            if constexpr (PERT) xin = nl_load<T, false>(in_i, lsb, o + lsb);
+        }
+        NLIn<T> x = xa;
+        if constexpr (PERT) x = nl_perturb<T>(xa, xia, pf);
+        T ref[FUSE == 3 ? NL_NUM_OUT : 1];
+        if constexpr (FUSE == 3) {   // requested before the physics, consumed after it
 #pragma unroll
-        for (int j = 0; j <= PD; ++j) {
-            const int k = k0 + j;
-            if (k < nz) {
-                if (k + PD < nz) {
-                    buf[(j + PD) % (PD + 1)] = nl_load<T, FUSE == 1>(in, lsb, o + uint32_t(PD) * lsb, keepq != 0);
-                    if constexpr (PERT)
-                        bufi[(j + PD) % (PD + 1)] = nl_load<T, false>(in_i, lsb, o + uint32_t(PD) * lsb);
-                }
-                NLIn<T> x = buf[j];
-                if constexpr (PERT) x = nl_perturb<T>(x, bufi[j], pf);
-                T ref[FUSE == 3 ? NL_NUM_OUT : 1];
-                if constexpr (FUSE == 3) {   // requested before the physics, consumed after it
-#pragma unroll
-                    for (int f = 0; f < NL_NUM_OUT; ++f) {
-                        const bool half = f == NL_OUT_FPLSL || f == NL_OUT_FPLSN || f == NL_OUT_FHPSL || f == NL_OUT_FHPSN;
-                        ref[f] = ldg(const_cast<const T*>(out.p[f]), half ? o + lsb : o);
-                    }
-                }
-                if constexpr (FUSE == 1) {
-                    x.qsat = nl_saturation<T>(e, xk, x.ap, x.t);
-                    if (live) stg(qsat_out, o, x.qsat);
-                }
-                const NLOut<T> r = nl_level<T, EVAP, LIN>(e, kc, xk, x, s_eta[k], s_scalm[k], crh, dt, aph_s, c);
-                if constexpr (FUSE == 3) {
-                    if (live) {
-                        acc[NL_OUT_CLC] += double(r.clc - ref[NL_OUT_CLC]);
-                        acc[NL_OUT_COVPTOT] += double(r.covptot - ref[NL_OUT_COVPTOT]);
-                        acc[NL_OUT_TND_Q] += double(r.tnd_q - ref[NL_OUT_TND_Q]);
-                        acc[NL_OUT_TND_T] += double(r.tnd_t - ref[NL_OUT_TND_T]);
-                        acc[NL_OUT_TND_QL] += double(r.tnd_ql - ref[NL_OUT_TND_QL]);
-                        acc[NL_OUT_TND_QI] += double(r.tnd_qi - ref[NL_OUT_TND_QI]);
-                        acc[NL_OUT_FPLSL] += double(r.rfln - ref[NL_OUT_FPLSL]);
-                        acc[NL_OUT_FPLSN] += double(r.sfln - ref[NL_OUT_FPLSN]);
-                        acc[NL_OUT_FHPSL] += double(enthalpy_diff<T>(r.rfln, e.RLVTT, ref[NL_OUT_FHPSL]));
-                        acc[NL_OUT_FHPSN] += double(enthalpy_diff<T>(r.sfln, e.RLSTT, ref[NL_OUT_FHPSN]));
-                    }
-                } else {
-                    if (live) nl_store<T>(out, e, lsb, o, r);
-                }
-                o += lsb;
+            for (int f = 0; f < NL_NUM_OUT; ++f) {
+                const bool half = f == NL_OUT_FPLSL || f == NL_OUT_FPLSN || f == NL_OUT_FHPSL || f == NL_OUT_FHPSN;
+                ref[f] = ldg(const_cast<const T*>(out.p[f]), half ? o + lsb : o);
             }
         }
+        if constexpr (FUSE == 1) {
+            x.qsat = nl_saturation<T>(e, xk, x.ap, x.t);
+            if (live) stg(qsat_out, o, x.qsat);
+        }
+        const NLOut<T> r = nl_level<T, EVAP, LIN>(e, kc, xk, x, s_eta[k], s_scalm[k], crh, dt, aph_s, c);
+        if constexpr (FUSE == 3) {
+            if (live) {
+                acc[NL_OUT_CLC] += double(r.clc - ref[NL_OUT_CLC]);
+                acc[NL_OUT_COVPTOT] += double(r.covptot - ref[NL_OUT_COVPTOT]);
+                acc[NL_OUT_TND_Q] += double(r.tnd_q - ref[NL_OUT_TND_Q]);
+                acc[NL_OUT_TND_T] += double(r.tnd_t - ref[NL_OUT_TND_T]);
+                acc[NL_OUT_TND_QL] += double(r.tnd_ql - ref[NL_OUT_TND_QL]);
+                acc[NL_OUT_TND_QI] += double(r.tnd_qi - ref[NL_OUT_TND_QI]);
+                acc[NL_OUT_FPLSL] += double(r.rfln - ref[NL_OUT_FPLSL]);
+                acc[NL_OUT_FPLSN] += double(r.sfln - ref[NL_OUT_FPLSN]);
+                acc[NL_OUT_FHPSL] += double(enthalpy_diff<T>(r.rfln, e.RLVTT, ref[NL_OUT_FHPSL]));
+                acc[NL_OUT_FHPSN] += double(enthalpy_diff<T>(r.sfln, e.RLSTT, ref[NL_OUT_FHPSN]));
+            }
+        } else {
+            if (live) nl_store<T>(out, e, lsb, o, r);
+        }
+        xa = xn;
+        if constexpr (PERT) xia = xin;
+        o += lsb;
     }
     if constexpr (FUSE == 3) {
         // workgroup reduction of the 10 sums: wave shuffle, then one LDS hop (the level table is no longer needed)

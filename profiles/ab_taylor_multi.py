@@ -81,10 +81,11 @@ def main():
         print(f"{name:>10s}: max |sum - first build's| / max|sum| = {np.abs(v - base).max() / np.abs(base).max():.2e}")
     times = {n: [] for n in libs}
     times.update({n + "+inc": [] for n in libs})
-    times["one-step x10"] = []
+    times.update({n + " one-step x10": [] for n in libs})
     for _ in range(rounds):
-        for name, lib in list(libs.items()) + [(n + "+inc", l) for n, l in libs.items()] + [("one-step x10", first)]:
-            fn = single if name == "one-step x10" else (multi_inc if name.endswith("+inc") else multi)
+        for name, lib in (list(libs.items()) + [(n + "+inc", l) for n, l in libs.items()]
+                          + [(n + " one-step x10", l) for n, l in libs.items()]):
+            fn = single if name.endswith("one-step x10") else (multi_inc if name.endswith("+inc") else multi)
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             for _ in range(3):
@@ -95,7 +96,7 @@ def main():
     print(f"ten step sizes of the Taylor test, {prec} {nx} columns, {rounds} interleaved rounds x 3:")
     for name, ts in times.items():
         ts = sorted(ts)
-        print(f"{name:>14s}: median {ts[len(ts) // 2]:8.3f} ms  min {ts[0]:8.3f} ms  ({ts[len(ts) // 2] / 10 * 1e3:7.1f} us per step size)")
+        print(f"{name:>22s}: median {ts[len(ts) // 2]:8.3f} ms  min {ts[0]:8.3f} ms  ({ts[len(ts) // 2] / 10 * 1e3:7.1f} us per step size)")
 
 
 if __name__ == "__main__":

@@ -244,3 +244,30 @@ def test_bench_lines_of_configs_3_and_4(gpu, config):
         assert set(r["stencils_one_step"]) == {"saturation", "state_increment", "cloudsc2_tl", "cloudsc2_ad"}
         for name in ("graph", "fused", "fused_graph"):
             assert "error" not in d["variants"][name] and d["variants"][name]["passed"] is True, (name, d["variants"][name])
+
+
+@pytest.mark.gpu
+def test_config5_whole_problem_on_one_gpu(gpu):
+    """BASELINE configs[4] at its FULL size - 4 194 304 fp32 columns x 137 levels, 60 GB of fields - resident on the one GPU
+    of the box (`--config 5 --gpus 1`; the 8-GPU split of the same global problem needs hardware the pool does not have):
+    the record names the configuration, every output is finite, and the NL kernel is the fp32 ring at a sane rate."""
+    p = _run("--config", "5", "--steps", "3", "--warmup", "1", "--cpu-cols", "0", "--no-extra-rooflines",
+             "--placement", "separate")
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.strip()][0])
+    assert d["n_gpus"] == 1 and d["dtype"] == "f32" and d["scaling"] == "strong"
+    assert d["config"]["columns_total"] == 4194304 == d["config"]["columns_per_gpu"] and "configs[4]" in d["config"]["workload"]
+    assert d["outputs_finite"] is True and d["value"] > 1.5e8
+    r = d["roofline"]
+    assert r["kernel"] == "cs2::nl_ring_kernel" and r["dtype"] == "f32" and r["columns"] == 4194304 and 0.4 < r["frac"] < 1.0
+    assert r["bytes_per_launch"] == 14268 * 4194304
+    # the same global problem split over 4 ranks (real kernels, the ranks share this GPU, gloo for the reductions): the
+    # shards are slices of ONE problem, so the validation norms of the split run are those of the whole
+    q = _run("--config", "5", "--gpus", "4", "--collective", "gloo", "--steps", "3", "--warmup", "1", "--cpu-cols", "0",
+             "--no-extra-rooflines", "--no-roofline-events", "--placement", "separate")
+    assert q.returncode == 0, q.stderr[-3000:]
+    d4 = json.loads([l for l in q.stdout.splitlines() if l.strip()][0])
+    assert d4["n_gpus"] == 4 and d4["rehearsal_ranks"] == 4 and d4["config"]["columns_per_gpu"] == 1048576
+    assert d4["config"]["columns_total"] == 4194304 and len(d4["per_rank_ms"]) == 4 and d4["outputs_finite"] is True
+    for name, v1 in d["validation_norm"].items():
+        assert d4["validation_norm"][name] == pytest.approx(v1, rel=1e-9, abs=1e-300), name

@@ -38,6 +38,14 @@ def core(args):
     mean = statistics.fmean(runtimes)
     std = statistics.stdev(runtimes) if len(runtimes) > 1 else 0.0
     print(f"\nThe test completed in {mean:.3f} ± {std:.3f} ms.")
+    io = ctx["io_config"]
+    if io.output_csv_file is not None:          # run_symmetry_test.py:106-121 (+ the build's GB/s and roofline columns)
+        from ..framework.output import write_performance_to_csv
+
+        seq = (["saturation", "cloudsc2_tl_incremented", "cloudsc2_ad"] if st.fused
+               else ["saturation", "state_increment", "cloudsc2_tl", "cloudsc2_ad"])
+        write_performance_to_csv(io.output_csv_file, io.host_name, cfg.precision, "ad-" + cfg.gt4py_config.backend,
+                                 ctx["nx"], cfg.num_threads, 1, cfg.num_runs, mean, std, 0, 0, stencils=seq)
     ctx.update(passed=ok, detail=st.last, runtimes_ms=runtimes, harness=st)
     return ctx
 

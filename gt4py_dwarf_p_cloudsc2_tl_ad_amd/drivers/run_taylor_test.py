@@ -39,6 +39,22 @@ def core(args):
     mean = statistics.fmean(runtimes)
     std = statistics.stdev(runtimes) if len(runtimes) > 1 else 0.0
     print(f"\nThe test completed in {mean:.3f} ± {std:.3f} ms.")
+    io = ctx["io_config"]
+    if io.output_csv_file is not None:          # run_taylor_test.py:109-124 (+ the build's GB/s and roofline columns)
+        from ..framework.output import write_performance_to_csv
+
+        n = len(tt.f2s)
+        head = ["saturation", "cloudsc2_nl"]
+        if tt.fused_all:
+            seq = head + ["cloudsc2_tl_incremented"] + ["cloudsc2_nl_taylor_multi"] * (-(-n // 5))
+        elif tt.fused_norms:
+            seq = head + ["state_increment", "cloudsc2_tl"] + ["cloudsc2_nl_taylor"] * n
+        elif tt.fused:
+            seq = head + ["state_increment", "cloudsc2_tl"] + ["cloudsc2_nl_perturbed"] * n
+        else:
+            seq = head + ["state_increment", "cloudsc2_tl"] + ["perturbed_state", "cloudsc2_nl"] * n
+        write_performance_to_csv(io.output_csv_file, io.host_name, cfg.precision, "tl-" + cfg.gt4py_config.backend,
+                                 ctx["nx"], cfg.num_threads, 1, cfg.num_runs, mean, std, 0, 0, stencils=seq)
     ctx.update(norms=norms, passed=ok, runtimes_ms=runtimes, harness=tt)
     return ctx
 

@@ -46,6 +46,24 @@ def test_mirror_taylor_driver_matches_reference_classes(oracle_numpy_backend, ca
         np.testing.assert_allclose(mine[:8], ref[:8], rtol=1e-7)
 
 
+def test_taylor_and_symmetry_drivers_write_the_performance_csv(oracle_numpy_backend, capsys, tmp_path):
+    """`--output-csv-file` of the two validation drivers (run_taylor_test.py:109-124 variant "tl-<backend>",
+    run_symmetry_test.py:106-121 variant "ad-<backend>"): the reference's columns + columns/s, GB/s, % of the roofline"""
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.drivers import run_symmetry_test, run_taylor_test
+
+    csv = tmp_path / "perf.csv"
+    run_taylor_test.main(["--backend", "numpy", "--num-cols", "32", "--num-runs", "2", "--output-csv-file", str(csv)])
+    run_symmetry_test.main(["--backend", "numpy", "--num-cols", "32", "--num-runs", "2", "--output-csv-file", str(csv)])
+    capsys.readouterr()
+    rows = [r.split(",") for r in csv.read_text().strip().splitlines()]
+    assert rows[0][:4] == ["host", "precision", "variant", "num_cols"] and len(rows) == 3
+    assert rows[1][2] == "tl-numpy" and rows[2][2] == "ad-numpy" and rows[1][3] == rows[2][3] == "32"
+    assert float(rows[1][7]) > 0 and float(rows[2][7]) > 0 and float(rows[1][12]) > 0      # mean ms, algorithmic GB/s
+    # bytes behind the GB/s column: 939 504 B per column for the Taylor run, 152 760 B for the symmetry call
+    assert float(rows[1][12]) * float(rows[1][7]) * 1e-3 * 1e9 / 32 == pytest.approx(939504, rel=1e-9)
+    assert float(rows[2][12]) * float(rows[2][7]) * 1e-3 * 1e9 / 32 == pytest.approx(152760, rel=1e-9)
+
+
 def test_mirror_symmetry_driver(oracle_numpy_backend, capsys):
     from gt4py_dwarf_p_cloudsc2_tl_ad_amd.drivers import run_symmetry_test
 

@@ -17,6 +17,8 @@ def core(args):
                       yrncl_params=p["yrncl"], yrphnc_params=p["yrphnc"], enable_checks=cfg.sympl_enable_checks,
                       gt4py_config=cfg.gt4py_config, ad_traj_fix=args.ad_traj_fix, graph=args.graph, fused=args.fused)
     ok = st(ctx["state"], ctx["dt"], enable_validation=cfg.enable_validation)   # warm-up + the validated call
+    if args.output_csv_file_stencils is not None and not args.graph:
+        cfg.gt4py_config.reset_exec_info()                    # run_symmetry_test.py:92: per-stencil HIP events from here on
     if args.tune_placement:
         # build extension: the ~80 fields of the test are re-placed in HBM where a whole run is fastest
         # (a captured HIP graph holds the OLD field addresses: candidates are timed eagerly, the graph is captured afterwards)
@@ -46,6 +48,12 @@ def core(args):
                else ["saturation", "state_increment", "cloudsc2_tl", "cloudsc2_ad"])
         write_performance_to_csv(io.output_csv_file, io.host_name, cfg.precision, "ad-" + cfg.gt4py_config.backend,
                                  ctx["nx"], cfg.num_threads, 1, cfg.num_runs, mean, std, 0, 0, stencils=seq)
+    if args.output_csv_file_stencils is not None:      # run_symmetry_test.py, end of main(): one row per stencil from exec_info
+        from ..framework.output import write_stencils_performance_to_csv
+
+        write_stencils_performance_to_csv(args.output_csv_file_stencils, ctx["io_config"].host_name, cfg.precision,
+                                          "ad-" + cfg.gt4py_config.backend, ctx["nx"], cfg.num_threads, cfg.num_runs,
+                                          cfg.gt4py_config.exec_info, key_patterns=["cloudsc", "increment", "saturation"])
     ctx.update(passed=ok, detail=st.last, runtimes_ms=runtimes, harness=st)
     return ctx
 

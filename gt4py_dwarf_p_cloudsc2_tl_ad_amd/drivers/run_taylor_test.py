@@ -18,6 +18,8 @@ def core(args):
                     yrphnc_params=p["yrphnc"], enable_checks=cfg.sympl_enable_checks, gt4py_config=cfg.gt4py_config,
                     fused=args.fused, fused_norms=args.fused_norms, fused_all=args.fused_all, graph=args.graph)
     norms = tt.run(ctx["state"], ctx["dt"])                  # warm-up; these norms are the validated ones
+    if args.output_csv_file_stencils is not None and not args.graph:
+        cfg.gt4py_config.reset_exec_info()                    # run_taylor_test.py:93: per-stencil HIP events from here on
     if args.tune_placement:
         # build extension: the ~90 fields of the test are re-placed in HBM where a whole run is fastest
         # (a captured HIP graph holds the OLD field addresses: candidates are timed eagerly and the graph is re-captured
@@ -55,6 +57,12 @@ def core(args):
             seq = head + ["state_increment", "cloudsc2_tl"] + ["perturbed_state", "cloudsc2_nl"] * n
         write_performance_to_csv(io.output_csv_file, io.host_name, cfg.precision, "tl-" + cfg.gt4py_config.backend,
                                  ctx["nx"], cfg.num_threads, 1, cfg.num_runs, mean, std, 0, 0, stencils=seq)
+    if args.output_csv_file_stencils is not None:      # run_taylor_test.py, end of main(): one row per stencil from exec_info
+        from ..framework.output import write_stencils_performance_to_csv
+
+        write_stencils_performance_to_csv(args.output_csv_file_stencils, ctx["io_config"].host_name, cfg.precision,
+                                          "tl-" + cfg.gt4py_config.backend, ctx["nx"], cfg.num_threads, cfg.num_runs,
+                                          cfg.gt4py_config.exec_info, key_patterns=["cloudsc", "increment", "perturbed", "saturation"])
     ctx.update(norms=norms, passed=ok, runtimes_ms=runtimes, harness=tt)
     return ctx
 

@@ -51,10 +51,16 @@ def test_taylor_and_symmetry_drivers_write_the_performance_csv(oracle_numpy_back
     run_symmetry_test.py:106-121 variant "ad-<backend>"): the reference's columns + columns/s, GB/s, % of the roofline"""
     from gt4py_dwarf_p_cloudsc2_tl_ad_amd.drivers import run_symmetry_test, run_taylor_test
 
-    csv = tmp_path / "perf.csv"
-    run_taylor_test.main(["--backend", "numpy", "--num-cols", "32", "--num-runs", "2", "--output-csv-file", str(csv)])
-    run_symmetry_test.main(["--backend", "numpy", "--num-cols", "32", "--num-runs", "2", "--output-csv-file", str(csv)])
+    csv, scsv = tmp_path / "perf.csv", tmp_path / "stencils.csv"
+    run_taylor_test.main(["--backend", "numpy", "--num-cols", "32", "--num-runs", "2", "--output-csv-file", str(csv),
+                          "--output-csv-file-stencils", str(scsv)])
+    run_symmetry_test.main(["--backend", "numpy", "--num-cols", "32", "--num-runs", "2", "--output-csv-file", str(csv),
+                            "--output-csv-file-stencils", str(scsv)])
     capsys.readouterr()
+    srows = [r.split(",") for r in scsv.read_text().strip().splitlines()[1:]]
+    calls = {(r[2], r[6]): int(r[7]) for r in srows}
+    assert calls[("tl-numpy", "cloudsc2_nl")] == 22 and calls[("tl-numpy", "perturbed_state")] == 20      # 2 runs x (1 + 10) / x 10
+    assert calls[("tl-numpy", "cloudsc2_tl")] == 2 and calls[("ad-numpy", "cloudsc2_ad")] == 2 and calls[("ad-numpy", "state_increment")] == 2
     rows = [r.split(",") for r in csv.read_text().strip().splitlines()]
     assert rows[0][:4] == ["host", "precision", "variant", "num_cols"] and len(rows) == 3
     assert rows[1][2] == "tl-numpy" and rows[2][2] == "ad-numpy" and rows[1][3] == rows[2][3] == "32"
@@ -271,6 +277,27 @@ def test_exec_info_and_stencil_csv_on_hip(gpu, tmp_path, capsys):
     for r in rows:
         assert int(r[7]) == 3 and 0.0 < float(r[8]) < 50.0          # 3 timed calls each, a sane mean in ms
         assert float(r[9]) > 0.0 and 0.0 < float(r[10]) < 100.0     # algorithmic GB/s, % of the 8 TB/s roofline
+
+
+@pytest.mark.gpu
+def test_stencil_csv_of_the_validation_drivers_on_hip(gpu, tmp_path, capsys):
+    """per-stencil CSV (HIP events in exec_info) of run_taylor_test in its fused-all mode and of run_symmetry_test --fused: the
+    build extensions appear under their own stencil names with their own byte counts"""
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.drivers import run_symmetry_test, run_taylor_test
+
+    csv = tmp_path / "stencils.csv"
+    run_taylor_test.main(["--backend", "hip", "--num-cols", "4096", "--num-runs", "2", "--fused-all",
+                          "--output-csv-file-stencils", str(csv)])
+    run_symmetry_test.main(["--backend", "hip", "--num-cols", "4096", "--num-runs", "2", "--fused",
+                            "--output-csv-file-stencils", str(csv)])
+    capsys.readouterr()
+    rows = [r.split(",") for r in csv.read_text().strip().splitlines()[1:]]
+    calls = {(r[2], r[6]): int(r[7]) for r in rows}
+    assert calls[("tl-hip", "cloudsc2_nl_taylor_multi")] == 2 and calls[("tl-hip", "cloudsc2_tl_incremented")] == 2
+    assert calls[("tl-hip", "cloudsc2_nl")] == 2 and ("tl-hip", "state_increment") not in calls
+    assert calls[("ad-hip", "cloudsc2_tl_incremented")] == 2 and calls[("ad-hip", "cloudsc2_ad")] == 2
+    for r in rows:
+        assert 0.0 < float(r[8]) < 50.0 and float(r[9]) > 0.0
 
 
 @pytest.mark.gpu

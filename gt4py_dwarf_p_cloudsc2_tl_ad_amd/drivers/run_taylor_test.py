@@ -48,7 +48,7 @@ def core(args):
         n = len(tt.f2s)
         head = ["saturation", "cloudsc2_nl"]
         if tt.fused_all:
-            seq = head + ["cloudsc2_tl_incremented"] + ["cloudsc2_nl_taylor_multi"] * (-(-n // 5))
+            seq = head + ["cloudsc2_tl_incremented", "cloudsc2_nl_taylor_multi"]
         elif tt.fused_norms:
             seq = head + ["state_increment", "cloudsc2_tl"] + ["cloudsc2_nl_taylor"] * n
         elif tt.fused:

@@ -12,7 +12,9 @@ FLOPS_PER_COLUMN = 1.0e3 * 137
 # Algorithmic HBM words per column (each input read once, each output written once; SURVEY.md 8a/8d, nz = 137)
 WORDS_PER_COLUMN = {"saturation": 411, "state_increment": 4416, "perturbed_state": 6624, "cloudsc2_nl": 3567,
                     "cloudsc2_nl_saturation": 3567, "cloudsc2_nl_perturbed": 5760, "cloudsc2_nl_taylor": 5760,
-                    "cloudsc2_nl_taylor_multi": 3567,      # per launch, increments formed in the kernel: 16 state + 10 reference fields
+                    # per CALL with the Taylor test's ten step sizes = two launches of five, increments formed in the kernel:
+                    # each launch reads the 16 state + 10 reference fields once
+                    "cloudsc2_nl_taylor_multi": 2 * 3567,
                     "cloudsc2_tl": 7134, "cloudsc2_tl_incremented": 4941, "cloudsc2_ad": 7134}
 HBM_PEAK_GBS = 8000.0   # MI355X spec peak the roofline columns are quoted against
 _WORD = {"double": 8, "single": 4}

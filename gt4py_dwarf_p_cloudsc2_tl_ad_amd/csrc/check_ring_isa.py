@@ -10,7 +10,8 @@ on the compiled gfx950 assembly (no GPU needed):
     cache-policy path (the in_qsat DMA, the optional pre-scan DMA), so lines cannot simply be counted; the kernel's
     control-flow graph is walked instead: on EVERY static path from one steady-state ring wait to the next there are
     >= NSTORE stores, the paths that issue any DMA issue >= NI of them, there is no ordinary load and no vector-memory
-    wait other than the three hand-written ones (NFULL, NHEAD, 0).
+    wait other than the three hand-written ones (NFULL, NHEAD, 0).  (RAGGED instantiations: the exec-masked stores of
+    a partly filled last wave are counted as issued - see `_cfg`.)
 
 Used by tests/test_ring_isa.py (CPU suite) and by `__graft_entry__.build()` whenever it really recompiles the library, so a
 library built by a different hipcc cannot ship with a wrong count.  `python check_ring_isa.py` runs it by hand."""
@@ -77,9 +78,12 @@ def check_tl_ring(asm):
     return seen
 
 
-def _cfg(lines):
+def _cfg(lines, execz_never_taken=False):
     """Nodes of a kernel's control-flow graph, split at labels, branches and vector-memory waits.  Every node is
-    (kind counts, wait value or None, successors)."""
+    (kind counts, wait value or None, successors).  `execz_never_taken`: drop the taken edge of `s_cbranch_execz` (the
+    skip around an exec-masked region) - for the RAGGED ring kernels, whose stores sit behind `if (live)`: a wave with
+    no live lane has retired at the top of the kernel, so inside the level loop that branch is never taken and the masked
+    stores are always issued."""
     starts = {0}
     label_at = {}
     for i, l in enumerate(lines):
@@ -103,7 +107,8 @@ def _cfg(lines):
         last = next((t for t in reversed(body) if t and not t.startswith(";")), "")
         m = re.match(r"s_(c?)branch\w* (\.LBB\d+_\d+)", last)
         if m:
-            succ.append(label_at[m.group(2)])
+            if not (execz_never_taken and last.startswith("s_cbranch_execz")):
+                succ.append(label_at[m.group(2)])
             if m.group(1):
                 succ.append(b)
         elif not last.startswith("s_endpgm"):
@@ -166,12 +171,12 @@ def check_nl_ring(asm):
     number of instantiations checked."""
     seen = 0
     for name, lines in _kernels(asm, "nl_ring_kernelI"):
-        m = re.search(r"nl_ring_kernelI([df])Lb[01]ELb[01]ELb[01]ELi(\d)ELb([01])E", name)
-        t, rd, satf = m.group(1), int(m.group(2)), m.group(3) == "1"
+        m = re.search(r"nl_ring_kernelI([df])Lb[01]ELb[01]ELb[01]ELi(\d)ELb([01])ELb([01])E", name)
+        t, rd, satf, ragged = m.group(1), int(m.group(2)), m.group(3) == "1", m.group(4) == "1"
         ni = 8 if t == "d" else 4
         nstore = 10
         nfull, nhead = (rd - 1) * ni + (rd - 2) * nstore, (rd - 1) * ni
-        nodes = _cfg(lines)
+        nodes = _cfg(lines, execz_never_taken=ragged)
         steady = [n for n, nd in nodes.items() if nd["wait"] == nfull and nd["ring_wait"]]
         assert steady, (name, f"no s_waitcnt vmcnt({nfull})")
         for n in steady:
@@ -180,7 +185,14 @@ def check_nl_ring(asm):
             # NI DMAs per level, + 1 for the pre-scan pair, + 1 static only: the default-policy / nt alternatives of the
             # in_qsat DMA, which hipcc lays out as a fall-through behind an always-taken s_cbranch_execnz
             assert ni <= r["dma_min_some"] and r["dma_max"] <= ni + 2, (name, "LDS-DMAs per level", r)
-            assert r["st"] == (want_st, want_st), (name, "stores per level", r)
+            if ragged:
+                # the level's stores sit behind `if (live)`: hipcc lowers that to exec-masked regions that a wave WITHOUT a
+                # live lane would skip (s_cbranch_execz / execnz in several shapes) - and such a wave has retired at the
+                # top of the kernel.  So only the maximum is held statically (all masked regions entered = every store of
+                # the level issued); the aligned instantiations above pin the exact count of the same source.
+                assert r["st"][1] == want_st, (name, "stores per level (ragged)", r)
+            else:
+                assert r["st"] == (want_st, want_st), (name, "stores per level", r)
             assert r["ld"] == 0, (name, "ordinary loads inside the level loop", r)
             assert r["waits"] <= {0, nhead, nfull}, (name, "vector-memory waits in the level loop", sorted(r["waits"]))
         seen += 1
@@ -193,7 +205,7 @@ def check_all(out_dir=None) -> dict:
         d = out_dir or tmp
         n_tl = check_tl_ring(compile_to_asm("cloudsc2_tl.hip", d))
         n_nl = check_nl_ring(compile_to_asm("cloudsc2_nl.hip", d))
-    assert n_tl == 8 and n_nl == 32, (n_tl, n_nl)      # T x REG x EVAP; T x EVAP x LIN x depth {3, 2} x SATF
+    assert n_tl == 8 and n_nl == 64, (n_tl, n_nl)      # T x REG x EVAP; T x EVAP x LIN x depth {3, 2} x SATF x RAGGED
     return {"tl_ring_kernel": n_tl, "nl_ring_kernel": n_nl}
 
 

@@ -637,7 +637,13 @@ __device__ __forceinline__ void ring_read(uint32_t a, uint32_t ta, uint32_t tb, 
 
 // SATF: the fused-saturation variant (FUSE = 1 of nl_kernel): in_qsat is not read - its half of the (ql, qsat) DMA
 // re-reads ql, the same bytes the other half fetches - but computed from (ap, t) and written to qsat_out.
-template <typename T, bool EVAP, bool LIN, bool PINK, int RD, bool SATF>
+// RAGGED (r03): nx is not a multiple of 64 - the last wave is partly filled.  Its dead lanes fetch the last DMA-wide group
+// of columns that holds a valid column instead of running off the row (the launcher guarantees lev_stride >= nx rounded up
+// to the DMA width, so that group lies inside every row; its columns beyond nx are row padding), compute on that copy and
+// do not store.  The stores are then exec-masked but still ISSUED by a
+// wave that has any live lane - and a wave without one retires at the top - so the hand-counted waits hold unchanged.
+// RAGGED = false is the code of the aligned whole-wave call, instruction for instruction.
+template <typename T, bool EVAP, bool LIN, bool PINK, int RD, bool SATF, bool RAGGED = false>
 __global__ void __launch_bounds__(kColBlock, 1)
 nl_ring_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, NL_NUM_IN> in,
                const T* __restrict__ eta, MPtrs<T, NL_NUM_OUT> out, T dt, T* __restrict__ qsat_out, int keepq) {
@@ -664,10 +670,11 @@ nl_ring_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtr
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wcol0 = xcd_block() * kColBlock + wave * 64;   // first column of this wave
-    if (wcol0 >= nx) return;                                // nx % 64 == 0 (launcher): whole waves retire; the only
-                                                            // workgroup barrier is inside build_level_table
+    if (wcol0 >= nx) return;                                // whole waves retire; the only workgroup barrier is inside
+                                                            // build_level_table
     const uint32_t lsb = uint32_t(ls) * uint32_t(sizeof(T));
-    const uint32_t colb = uint32_t(wcol0 + lane) * uint32_t(sizeof(T));
+    const bool live = !RAGGED || wcol0 + lane < nx;         // RAGGED: lanes beyond nx shadow the last column, stores masked
+    const uint32_t colb = uint32_t(live ? wcol0 + lane : nx - 1) * uint32_t(sizeof(T));
 
     // Tropopause pre-scan (:107-111), overlapped with the sweep.  crh2 (:166-186) is 1 on every level with
     // eta <= 0.1 whatever trpaus (>= 0.1) turns out to be, i.e. on all levels above the window [klo, khi] of a
@@ -694,10 +701,12 @@ nl_ring_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtr
     c.covptot = T(0.0);
     c.aph_k = ldg(in.p[NL_IN_APH], colb);
     const T aph_s = EVAP ? ldg(in.p[NL_IN_APH], uint32_t(nz) * lsb + colb) : T(1.0);
-    stg(out.p[NL_OUT_FPLSL], colb, T(0.0));
-    stg(out.p[NL_OUT_FPLSN], colb, T(0.0));
-    stg(out.p[NL_OUT_FHPSL], colb, T(0.0));
-    stg(out.p[NL_OUT_FHPSN], colb, T(0.0));
+    if (live) {
+        stg(out.p[NL_OUT_FPLSL], colb, T(0.0));
+        stg(out.p[NL_OUT_FPLSN], colb, T(0.0));
+        stg(out.p[NL_OUT_FHPSL], colb, T(0.0));
+        stg(out.p[NL_OUT_FHPSN], colb, T(0.0));
+    }
     // consume the prologue's ordinary loads BEFORE the first DMA is issued: hipcc drains vmcnt(0) at the first use of
     // an ordinary load's result while an LDS-DMA is in flight, which would empty the ring inside level 0
     pin_vgpr(c.aph_k);
@@ -708,6 +717,10 @@ nl_ring_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtr
     // aph and lu are read one half level below (aph[k+1], lu[k+1]: :130, :212)
     constexpr int LPG = 64 / G::NPL;   // lanes per group
     const int g = lane / LPG, l = lane % LPG;
+    // first of this lane's NPL columns; RAGGED: a lane whose group lies beyond nx fetches the last group that holds a valid
+    // column instead (a group boundary, so 16-byte aligned like every other source; inside the row: see the launcher)
+    const int last_group = ((nx - 1) / G::NPL) * G::NPL;
+    const int dcol = (RAGGED && wcol0 + G::NPL * l > last_group) ? last_group : wcol0 + G::NPL * l;
     const char* src[G::NI];
 #pragma unroll
     for (int i = 0; i < G::NI; ++i) {
@@ -721,11 +734,11 @@ nl_ring_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtr
             }
         if (SATF && f == NL_IN_QSAT) base = in.p[NL_IN_QL];
         const uint32_t lev1 = (f == NL_IN_APH || f == NL_IN_LU) ? lsb : 0u;
-        src[i] = reinterpret_cast<const char*>(base) + (uint32_t(wcol0 + G::NPL * l) * uint32_t(sizeof(T)) + lev1);
+        src[i] = reinterpret_cast<const char*>(base) + (uint32_t(dcol) * uint32_t(sizeof(T)) + lev1);
     }
     // the pre-scan pair: lane groups alternate between t and tnd_cml_t of level klo + 1 + (level being fetched)
     const char* src_ps = reinterpret_cast<const char*>((g & 1) ? in.p[NL_IN_TND_CML_T] : in.p[NL_IN_T]) +
-                         (uint32_t(wcol0 + G::NPL * l) * uint32_t(sizeof(T)) + uint32_t(klo + 1) * lsb);
+                         (uint32_t(dcol) * uint32_t(sizeof(T)) + uint32_t(klo + 1) * lsb);
     const int nps_dma = overlap ? nps : 0;
     // LDS: [eta | scalm table][pad][wave 0: RD slots][wave 1: RD slots] ...
     const uint32_t tab_bytes = (2u * uint32_t(nz + 1) * uint32_t(sizeof(T)) + 1023u) & ~1023u;
@@ -791,10 +804,10 @@ nl_ring_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtr
         }
         if constexpr (SATF) {
             x.qsat = nl_saturation<T>(e, xk, x.ap, x.t);
-            stg(qsat_out, o, x.qsat);   // an 11th store per level: not counted in NFULL (under-counting is safe)
+            if (live) stg(qsat_out, o, x.qsat);   // an 11th store per level: not counted in NFULL (under-counting is safe)
         }
         const NLOut<T> r = nl_level<T, EVAP, LIN>(e, kc, xk, x, eta_k, scalm_k, crh, dt, aph_s, c);
-        nl_store<T>(out, e, lsb, o, r);
+        if (live) nl_store<T>(out, e, lsb, o, r);
         o += lsb;
         slot = slot + 1 == RD ? 0 : slot + 1;
         pslot = pslot + 1 == RD ? 0 : pslot + 1;
@@ -842,7 +855,13 @@ int launch_nl(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
     // more, LDS occupancy matters more than depth - depth 2 keeps two workgroups resident per CU (131 072 columns:
     // 655 us vs 692 us at depth 3; 262 144: 1 286 vs 1 350 us).
     bool ring_deep = true;
-    bool ring = fuse <= 1 && nx % 64 == 0 && nz >= CS2_NL_RING && (ls * int64_t(sizeof(T))) % 16 == 0;
+    // 16-byte aligned rows that hold whole DMA-wide groups of columns up to the last valid one (lev_stride >= nx rounded up
+    // to 2 fp64 / 4 fp32 columns: `storage.zeros` pads the level pitch to 512 B); a partly filled last wave takes the
+    // RAGGED instantiation
+    constexpr int kNPL = RingGeom<T>::NPL;
+    bool ring = fuse <= 1 && nx > 0 && nz >= CS2_NL_RING && (ls * int64_t(sizeof(T))) % 16 == 0 &&
+                ls >= int64_t((nx + kNPL - 1) / kNPL) * kNPL;
+    const bool ragged = nx % 64 != 0;
     for (int i = 0; i < NL_NUM_IN && ring; ++i)
         ring = (fuse == 1 && i == NL_IN_QSAT) || reinterpret_cast<uintptr_t>(in[i]) % 16 == 0;
     if (ring) {
@@ -866,7 +885,12 @@ int launch_nl(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
         const size_t rsmem = tab + size_t(kColBlock / 64) * depth * G::SLOT;
 #define CS2_NL_RING_LAUNCH(EV, LN, RD, SF)                                                                           \
     do {                                                                                                             \
-        auto kern = nl_ring_kernel<T, EV, LN, sizeof(T) == 8, RD, SF>;                                               \
+        if (ragged) CS2_NL_RING_LAUNCH_R(EV, LN, RD, SF, true);                                                      \
+        else CS2_NL_RING_LAUNCH_R(EV, LN, RD, SF, false);                                                            \
+    } while (0)
+#define CS2_NL_RING_LAUNCH_R(EV, LN, RD, SF, RG)                                                                     \
+    do {                                                                                                             \
+        auto kern = nl_ring_kernel<T, EV, LN, sizeof(T) == 8, RD, SF, RG>;                                           \
         /* > 64 KB of dynamic LDS needs the opt-in: once per instantiation, device and size */                       \
         static std::atomic<size_t> attr_set[kMaxDevices] = {};                                                       \
         if (!lds_opt_in(kern, attr_set, dev, rsmem)) return -1;                                                      \
@@ -890,7 +914,8 @@ int launch_nl(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
         }
 #undef CS2_NL_RING_FLAGS
 #undef CS2_NL_RING_LAUNCH
-        note_kernel("cs2::nl_ring_kernel");
+#undef CS2_NL_RING_LAUNCH_R
+        note_kernel(ragged ? "cs2::nl_ring_kernel<ragged>" : "cs2::nl_ring_kernel");
         return hipGetLastError() == hipSuccess ? 0 : -1;
     }
 #endif

@@ -135,7 +135,8 @@ def setup(args) -> Dict[str, Any]:
         state = {}
         for name, t in s.items():
             kdim = K - 1 / 2 if name == "f_aph" else K
-            state[name] = DataArray(storage.logical_view(t), (I, J, kdim), "")
+            # (copied into a storage of this build: every field of a call must share one level pitch, storage.level_pitch)
+            state[name] = DataArray(storage.from_klayout(t, gcfg.dtypes.float, device), (I, J, kdim), "")
         dt = timedelta(seconds=3600.0)
         groups = _groups_from_defaults()
         source = "synthetic columns (seed 20240807) + synthetic-parameters"

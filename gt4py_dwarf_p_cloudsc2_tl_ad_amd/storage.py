@@ -43,6 +43,27 @@ def torch_dtype(dtype: Any) -> torch.dtype:
     return _TORCH_DTYPES[np.dtype(dtype)]
 
 
+#: every level of a field starts on a 512-byte boundary of its storage: one wave's request for 64 fp64 columns.  For nx
+#: a multiple of 64 (fp64) / 128 (fp32) columns - every BASELINE size - that is the dense layout; for any other nx the
+#: level pitch is padded, which keeps rows aligned for the LDS-DMA load path (cloudsc2_nl takes its ring kernel for ANY
+#: nx then; measured at 65 500 fp64 columns: 330 us padded against 378-388 us dense and 410 us on the register path)
+ROW_ALIGN_BYTES = 512
+
+
+def level_pitch(nx: int, dtype: Any) -> int:
+    """columns from one level to the next (lev_stride) of the storages this module allocates: nx rounded up so that a level
+    is a multiple of ROW_ALIGN_BYTES"""
+    item = torch.empty((), dtype=torch_dtype(dtype)).element_size()
+    per = max(1, ROW_ALIGN_BYTES // item)
+    return -(-int(nx) // per) * per
+
+
+def _padded_kc(nx: int, nz: int, dt: torch.dtype, dev: torch.device) -> torch.Tensor:
+    """zero-initialised (nz+1, nx) [level][column] window of a (nz+1, level_pitch) allocation"""
+    ls = level_pitch(nx, dt)
+    return torch.zeros((nz + 1, ls), dtype=dt, device=dev)[:, :nx]
+
+
 def logical_view(kc: torch.Tensor) -> torch.Tensor:
     """(nz+1, nx) physical tensor -> (nx, 1, nz+1) logical view (no copy)."""
     if kc.dim() != 2:
@@ -74,7 +95,8 @@ class FieldArena:
         item = torch.empty((), dtype=self.dtype).element_size()
         if self.stagger % 16 or self.capacity < 1:
             raise ValueError("stagger must be a multiple of 16 bytes (the kernels' 16-byte load paths), capacity >= 1")
-        fbytes = (self.nz + 1) * self.nx * item
+        self.ls = level_pitch(self.nx, self.dtype)
+        fbytes = (self.nz + 1) * self.ls * item
         self.slab = -(-(fbytes + self.STAGGER_WRAP) // self.SLAB_ALIGN) * self.SLAB_ALIGN + int(extra_spacing)
         self._item = item
         self._buf = torch.zeros((self.capacity * self.slab + self.SLAB_ALIGN) // item, dtype=self.dtype, device=self.device)
@@ -94,8 +116,8 @@ class FieldArena:
             raise RuntimeError(f"FieldArena is full ({self.capacity} fields)")
         o = (self._base + self.offset_of(self._next)) // self._item
         self._next += 1
-        n = (self.nz + 1) * self.nx
-        return logical_view(self._buf[o:o + n].view(self.nz + 1, self.nx))
+        n = (self.nz + 1) * self.ls
+        return logical_view(self._buf[o:o + n].view(self.nz + 1, self.ls)[:, :self.nx])
 
 
 def plan_placement_grid(n: int, slab: int, free_bytes: Optional[int], *, spacings, staggers, shifts_mb, wide_spacings,
@@ -156,7 +178,8 @@ def tune_placement(nx: int, nz: int, dtype: Any, device: Any, order, sources, la
     item = torch.empty((), dtype=dt).element_size()
     n = len(order)
     two_mb = FieldArena.SLAB_ALIGN
-    slab = -(-((nz + 1) * nx * item + FieldArena.STAGGER_WRAP) // two_mb) * two_mb
+    ls = level_pitch(nx, dt)
+    slab = -(-((nz + 1) * ls * item + FieldArena.STAGGER_WRAP) // two_mb) * two_mb
     # what is free on THIS device now (one process per GPU: every rank sizes its arena against its own device)
     free_bytes = torch.cuda.mem_get_info(dev)[0] if dev.type == "cuda" else None
     grid, arena_need, spacings = plan_placement_grid(
@@ -164,13 +187,13 @@ def tune_placement(nx: int, nz: int, dtype: Any, device: Any, order, sources, la
         wide_shifts_mb=wide_shifts_mb, max_arena_bytes=max_arena_bytes, max_shift_spans=max_shift_spans)
     buf = torch.zeros(arena_need // item, dtype=dt, device=dev)
     base = (-buf.data_ptr()) % two_mb
-    count = (nz + 1) * nx
+    count = (nz + 1) * ls
 
     def place(e, st, sh=0):
         fields = {}
         for i, name in enumerate(order):
             o = (base + sh + i * (slab + e * two_mb) + (i * st) % FieldArena.STAGGER_WRAP) // item
-            fields[name] = logical_view(buf[o:o + count].view(nz + 1, nx))
+            fields[name] = logical_view(buf[o:o + count].view(nz + 1, ls)[:, :nx])
         for name, src in sources.items():
             if src is not None:
                 klayout(fields[name]).copy_(src)
@@ -274,7 +297,7 @@ def _arena_for(nx: int, nz: int, dtype: torch.dtype, device: torch.device) -> Op
     a = _arenas.get(key)
     if a is None or a.free_slots == 0:
         item = torch.empty((), dtype=dtype).element_size()
-        slab = -(-((nz + 1) * nx * item + FieldArena.STAGGER_WRAP) // FieldArena.SLAB_ALIGN) * FieldArena.SLAB_ALIGN
+        slab = -(-((nz + 1) * level_pitch(nx, dtype) * item + FieldArena.STAGGER_WRAP) // FieldArena.SLAB_ALIGN) * FieldArena.SLAB_ALIGN
         cap = max(1, min(_ARENA_CAPACITY, _ARENA_MAX_BYTES // slab))
         a = _arenas[key] = FieldArena(nx, nz, dtype, device, cap)
     return a
@@ -286,6 +309,8 @@ def zeros(nx: int, nz: int, dtype: Any, device: Any) -> torch.Tensor:
     arena = _arena_for(int(nx), int(nz), dt, dev) if dt.is_floating_point else None
     if arena is not None:
         return arena.zeros()
+    if dev.type == "cuda" and dt.is_floating_point:
+        return logical_view(_padded_kc(int(nx), int(nz), dt, dev))
     return logical_view(torch.zeros((nz + 1, nx), dtype=dt, device=dev))
 
 
@@ -304,6 +329,10 @@ def from_klayout(array_kc: Any, dtype: Any, device: Any) -> torch.Tensor:
             f = arena.zeros()
             klayout(f).copy_(t)
             return f
+    if t.dim() == 2 and dt.is_floating_point and dev.type == "cuda":
+        kc = _padded_kc(int(t.shape[1]), int(t.shape[0]) - 1, dt, dev)
+        kc.copy_(t)
+        return logical_view(kc)
     t = t.to(device=dev, dtype=dt).contiguous()
     return logical_view(t)
 

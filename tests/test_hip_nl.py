@@ -263,7 +263,7 @@ def test_taylor_reduction_variant_matches_separate_calls(gpu, dtype):
     ext = externals()
     fields, eta, dt = nl_case(nx, dtype=dtype)
     dev = to_device(fields, gpu)
-    inc = {k + "_i": (0.01 * v).clone() for k, v in dev.items()}
+    inc = {k + "_i": storage.from_klayout(0.01 * storage.klayout(v), dtype, gpu) for k, v in dev.items()}   # same level pitch
     eta_d = torch.as_tensor(eta, device=gpu)
     com = dict(in_eta=eta_d, dt=dt, origin=(0, 0, 0), domain=(nx, 1, nz + 1), validate_args=True, exec_info=None)
     ref = {"out_" + n: storage.zeros(nx, nz, dtype, gpu) for n in NL_OUT}
@@ -486,3 +486,50 @@ def test_fused_perturbation_with_general_increments(gpu, sw):
     want = np.array([float((outs["out_" + n].double() - ref["out_" + n].double()).sum()) for n in NL_OUT])
     mag = np.array([float((outs["out_" + n].double() - ref["out_" + n].double()).abs().sum()) for n in NL_OUT])
     assert np.all(np.abs(got - want) <= 1e-12 * mag + 1e-300), (got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,nx", [(np.float64, 1), (np.float64, 2), (np.float64, 66), (np.float64, 333), (np.float64, 1000),
+                                      (np.float64, 65499), (np.float64, 65500), (np.float32, 3), (np.float32, 4),
+                                      (np.float32, 68), (np.float32, 1001), (np.float32, 20004)])
+def test_ragged_last_wave_takes_the_ring(gpu, dtype, nx):
+    """r03: a call whose nx is NOT a multiple of 64 keeps the LDS-ring path (`nl_ring_kernel<.., RAGGED>`) as long as its rows
+    are 16-byte aligned and hold the last DMA-wide group of columns (lev_stride >= nx rounded up to 2 fp64 / 4 fp32 columns -
+    what `storage.zeros` allocates): the dead lanes of the partly filled last wave fetch that group, compute on the copy and
+    do not store.  Held against the oracle; the storages are wider than nx and the columns beyond nx must stay untouched - a
+    store that ran off the window would show there, a DMA that ran off the row would fault."""
+    import torch
+
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd import _lib, storage
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.stencils import compile_stencil
+
+    nz = 137
+    per16 = 16 // np.dtype(dtype).itemsize
+    pad = 8 + (-(nx + 8)) % per16               # lev_stride = nx + pad: a multiple of the DMA width, rows 16-byte aligned
+    ext = externals()
+    fields, eta, dt = nl_case(nx, dtype=dtype, seed=41)
+    big = nx > 4096
+    want = run_oracle_nl({k: v[:, :2048] for k, v in fields.items()} if big else fields, eta, dt, ext)
+    td = storage.torch_dtype(dtype)
+    wide_in = {k: torch.full((nz + 1, nx + pad), 7.0, dtype=td, device=gpu) for k in fields}
+    for k, v in fields.items():
+        wide_in[k][:, :nx] = torch.as_tensor(v, device=gpu)
+    wide_out = {"out_" + n: torch.full((nz + 1, nx + pad), -3.0, dtype=td, device=gpu) for n in NL_OUT}
+    view = lambda d: {k: storage.logical_view(v[:, :nx]) for k, v in d.items()}  # noqa: E731
+    compile_stencil("cloudsc2_nl", ext)(**view(wide_in), **view(wide_out), in_eta=torch.as_tensor(eta, device=gpu), dt=dt,
+                                         origin=(0, 0, 0), domain=(nx, 1, nz + 1), validate_args=True, exec_info=None)
+    torch.cuda.synchronize()
+    assert _lib.last_kernel() == ("cs2::nl_ring_kernel<ragged>" if nx % 64 else "cs2::nl_ring_kernel")
+    ncmp = 2048 if big else nx
+    for n in NL_OUT:
+        got = wide_out["out_" + n].cpu().numpy()
+        k = nz + 1 if n.startswith("f") else nz
+        assert_close(f"ragged ring out_{n} nx={nx}", got[:k, :ncmp], want[n][:k], dtype)
+        assert np.all(got[:, nx:] == -3.0), n                              # nothing written beyond the window
+        assert np.all(np.isfinite(got[:k, :nx])), n
+    if big:      # the last (partly filled) wave too: its columns against the oracle on those columns alone
+        tail = {k: np.ascontiguousarray(v[:, nx - 60:]) for k, v in fields.items()}
+        want_t = run_oracle_nl(tail, eta, dt, ext)
+        for n in NL_OUT:
+            k = nz + 1 if n.startswith("f") else nz
+            assert_close(f"ragged ring tail out_{n}", wide_out["out_" + n][:k, nx - 60:nx].cpu().numpy(), want_t[n][:k], dtype)

@@ -17,7 +17,7 @@ def test_field_arena_geometry_on_the_host():
         a.zeros()
     two_mb = 2 << 20
     for i, f in enumerate(fields):
-        assert f.shape == (100, 1, 138) and storage.field_geometry(f) == (100, 138, 100)
+        assert f.shape == (100, 1, 138) and storage.field_geometry(f) == (100, 138, 128)     # level pitch padded to 512 B
         assert f.data_ptr() % two_mb == (i * 2304) % 65536          # 2 MB slab start + i x 2 304 B stagger
         assert float(f.abs().sum()) == 0.0
     assert fields[1].data_ptr() - fields[0].data_ptr() == a.slab + 2304 and a.slab % two_mb == 0

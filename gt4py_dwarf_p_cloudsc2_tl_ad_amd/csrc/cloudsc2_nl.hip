@@ -13,7 +13,7 @@
 //
 // Two kernels share nl_level / nl_store: nl_kernel (register prefetch; any shape, and the perturbed / Taylor fused
 // variants) and nl_ring_kernel (LDS-DMA ring, two levels in flight, tropopause pre-scan overlapped with the sweep;
-// whole waves and 16-byte aligned rows - the path the headline configuration takes).  launch_nl picks.
+// 16-byte aligned rows, any nx - the path the headline configuration takes).  launch_nl picks.
 //
 // Template flags: EVAP = LEVAPLS2 or LDRAIN1D (precipitation evaporation block :288-321 and the
 // 1.9*RCLCRIT / 1e-4 thresholds :250-266), LIN = LPHYLIN or LDRAIN1D (:141-155).
@@ -531,8 +531,8 @@ nl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
 //     retires in order on gfx9 (the wait used is one level of stores stricter than that, see NFULL).  The wait and the LDS reads live in ONE asm statement with a memory clobber: hipcc
 //     would otherwise drain vmcnt(0) before every LDS read that follows an LDS-DMA, and no store may move across
 //     the wait (the count must never exceed the operations really issued after level k's DMAs).
-// Used when the launcher can guarantee 16-byte aligned rows and whole waves (launch_nl); every other call takes
-// the register-prefetch kernel above.  Results are bit-identical (same arithmetic on the same words).
+// Used when the launcher can guarantee 16-byte aligned rows that hold the last DMA-wide column group (launch_nl; a partly
+// filled last wave: RAGGED); every other call takes the register-prefetch kernel above.  Results are bit-identical (same arithmetic on the same words).
 #ifndef CS2_NL_RING
 #define CS2_NL_RING 3   // slots per wave (levels in flight + the one being computed); 0 disables the variant
 #endif

@@ -23,7 +23,6 @@ part of h5py's the reader path uses: `File(path)` is a read-only mapping name ->
 from __future__ import annotations
 
 import mmap
-import struct
 from collections.abc import Mapping
 from typing import Dict, Iterator, Tuple
 

@@ -7,7 +7,7 @@ sums the reference's TaylorTest forms from them (tangent_linear/validation.py:23
 import numpy as np
 import pytest
 
-from helpers import NL_IN, NL_OUT, assert_close, externals, nl_case, nlev_of, oracle, run_oracle_nl, to_device
+from helpers import NL_OUT, assert_close, externals, nl_case, nlev_of, oracle, run_oracle_nl, to_device
 
 pytestmark = pytest.mark.gpu
 

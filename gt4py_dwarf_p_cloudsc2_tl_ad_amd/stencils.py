@@ -99,6 +99,14 @@ class HipStencil:
                     raise ValueError(f"{self.name}: argument {n} has (nx, nlev, lev_stride) = {g}, "
                                      f"expected {(nx, nlev, ls)}")
             self._check_disjoint(fields, nx, nlev, ls, first.element_size())
+        elif nlev > 1:
+            # ALWAYS checked, validate_args or not (a few microseconds): the C ABI takes ONE level stride for every field of
+            # the call, and storages may carry a padded level pitch (storage.level_pitch) - a field allocated another way
+            # (a dense torch tensor beside storage.zeros fields at a ragged nx) would be addressed with the wrong stride
+            for n, f in fields.items():
+                if f.stride(2) != ls:
+                    raise ValueError(f"{self.name}: argument {n} has level stride {f.stride(2)}, the call's is {ls} - "
+                                     "allocate every field of a call the same way (storage.zeros / storage.from_klayout)")
         return nx, nz, ls, first.dtype, first.device
 
     def _check_disjoint(self, fields: Mapping[str, torch.Tensor], nx: int, nlev: int, ls: int, itemsize: int) -> None:

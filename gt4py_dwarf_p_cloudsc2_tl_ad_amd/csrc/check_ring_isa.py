@@ -1,4 +1,5 @@
-"""Build-time guard of the hand-counted `s_waitcnt vmcnt(N)` in the LDS-ring kernels (cloudsc2_nl.hip, cloudsc2_tl.hip).
+"""Build-time guard of the compiled level loops: the hand-counted `s_waitcnt vmcnt(N)` of the LDS-ring kernels
+(cloudsc2_nl.hip, cloudsc2_tl.hip) and the prefetch distance of the register-path kernels.
 
 The ring kernels wait for "all but the N youngest vector-memory operations"; N is counted by hand from what the level loop
 issues (NI LDS-DMAs + the level's stores).  That count is only right for the code hipcc actually emitted, so it is checked
@@ -12,6 +13,10 @@ on the compiled gfx950 assembly (no GPU needed):
     >= NSTORE stores, the paths that issue any DMA issue >= NI of them, there is no ordinary load and no vector-memory
     wait other than the three hand-written ones (NFULL, NHEAD, 0).  (RAGGED instantiations: the exec-masked stores of
     a partly filled last wave are counted as issued - see `_cfg`.)
+
+  * register-path kernels (tl_kernel, nl_kernel, nl_taylor_multi_kernel, ad_kernel; `check_prefetch_distance`): in every
+    level loop the first wait that reaches into the batch of prefetch loads for the next level comes at least 60
+    instructions behind the batch - i.e. nothing consumes a prefetched word at the load site.
 
 Used by tests/test_ring_isa.py (CPU suite) and by `__graft_entry__.build()` whenever it really recompiles the library, so a
 library built by a different hipcc cannot ship with a wrong count.  `python check_ring_isa.py` runs it by hand."""
@@ -199,14 +204,83 @@ def check_nl_ring(asm):
     return seen
 
 
+def _is_instr(line):
+    t = line.strip()
+    return bool(t) and not t.startswith((";", ".", "//")) and not t.endswith(":")
+
+
+def check_prefetch_distance(asm, prefix, min_instr=60, min_batch=14, skip=None):
+    """The register-path kernels (tl_kernel, ad_kernel, nl_kernel, nl_taylor_multi_kernel) request level k+1's words
+    before level k is computed.  That only hides latency if nothing WAITS for those words until the level's arithmetic
+    is done.  Two things made hipcc wait early in r03 (docs/TUNING_LOG.md 3.9): arithmetic on a loaded word at the load
+    site (cloudsc2_ad's flux forcings: `s_waitcnt vmcnt(11)` 10 instructions behind the batch of 26 loads, on every level
+    of sweep 2) and a rotating register buffer (cloudsc2_nl, fixed earlier in r03).  Checked on the compiled ISA: inside
+    every level loop, the first vector-memory wait in program order that reaches into a batch of >= `min_batch` ordinary
+    loads (`vmcnt(N)` with N below the operations issued since the batch began) comes at least `min_instr` instructions
+    behind it.  Not checked: nl_kernel<EVAP = true, FUSE = 3> (the opt-in fused-norms kernel with the evaporation block no
+    driver enables: at 256 VGPRs hipcc sinks loads to their uses there).  Returns the number of (kernel, batch) pairs checked."""
+    seen = 0
+    for name, lines in _kernels(asm, prefix):
+        if skip and re.search(skip, name):
+            continue
+        labels = {m.group(1): i for i, l in enumerate(lines) if (m := re.match(r"(\.LBB\d+_\d+):", l.strip()))}
+        i = 0
+        while i < len(lines):
+            if "global_load_dword" not in lines[i] or "global_load_lds" in lines[i]:
+                i += 1
+                continue
+            # a batch: loads separated by at most 24 other instructions (address arithmetic, v_readlane of spilled pointers)
+            j, last, n, gap = i, i, 0, 0
+            while j < len(lines) and gap <= 24:
+                if "global_load_dword" in lines[j] and "global_load_lds" not in lines[j]:
+                    last, n, gap = j, n + 1, 0
+                elif _is_instr(lines[j]):
+                    gap += 1
+                j += 1
+            loop = _innermost_loop_around(lines, last)
+            # level loops only (hundreds of instructions of physics): the tropopause pre-scan's short loop consumes what it loads
+            if n >= min_batch and loop is not None and loop[1] - loop[0] >= 600:
+                # the first wait that reaches INTO the batch: vmcnt(N) with N below the operations issued since its first load
+                # (program order: unconditional branches are followed, conditional ones fall through)
+                dist, k, issued, hops = 0, last + 1, n, 0
+                while k < len(lines):
+                    m = re.search(r"s_waitcnt.*vmcnt\((\d+)\)", lines[k])
+                    if m and int(m.group(1)) < issued:
+                        break
+                    b = re.match(r"\s*s_branch (\.LBB\d+_\d+)", lines[k])
+                    if b and b.group(1) in labels and hops < 64:
+                        k, hops = labels[b.group(1)], hops + 1
+                        continue
+                    issued += "global_load" in lines[k] or "global_store" in lines[k]
+                    dist += _is_instr(lines[k])
+                    k += 1
+                assert k == len(lines) or dist >= min_instr, (
+                    name, f"a batch of {n} loads in a level loop is waited for {dist} instructions later", lines[k].strip())
+                seen += 1
+            i = last + 1
+    return seen
+
+
 def check_all(out_dir=None) -> dict:
     """Compile both ring sources to assembly and check every instantiation; raises AssertionError on a mismatch."""
     with tempfile.TemporaryDirectory() as tmp:
         d = out_dir or tmp
-        n_tl = check_tl_ring(compile_to_asm("cloudsc2_tl.hip", d))
-        n_nl = check_nl_ring(compile_to_asm("cloudsc2_nl.hip", d))
+        asm_tl, asm_nl = compile_to_asm("cloudsc2_tl.hip", d), compile_to_asm("cloudsc2_nl.hip", d)
+        asm_ad = compile_to_asm("cloudsc2_ad.hip", d)
+    n_tl = check_tl_ring(asm_tl)
+    n_nl = check_nl_ring(asm_nl)
     assert n_tl == 8 and n_nl == 64, (n_tl, n_nl)      # T x REG x EVAP; T x EVAP x LIN x depth {3, 2} x SATF x RAGGED
-    return {"tl_ring_kernel": n_tl, "nl_ring_kernel": n_nl}
+    pf = {"tl_kernel": check_prefetch_distance(asm_tl, "9tl_kernelI"),
+          "nl_kernel": check_prefetch_distance(asm_nl, "9nl_kernelI", skip=r"Lb1ELb[01]ELb[01]ELi3E"),
+          "nl_taylor_multi_kernel": check_prefetch_distance(asm_nl, "nl_taylor_multi_kernelI"),
+          "ad_kernel": check_prefetch_distance(asm_ad, "9ad_kernelI")}
+    # the batch detection is a heuristic (loads a few instructions apart, loops of >= 600 lines): it must have seen every
+    # instantiation's level loop(s) - first of all the ones the drivers' defaults run (fp64, LREGCL, no evaporation)
+    assert check_prefetch_distance(asm_tl, "9tl_kernelIdLb1ELb0ELb0E") == 1, "cloudsc2_tl fp64 default: level loop not seen"
+    assert check_prefetch_distance(asm_ad, "9ad_kernelIdLb1ELb0ELb0E") == 2, "cloudsc2_ad fp64 default: two sweeps not seen"
+    assert check_prefetch_distance(asm_nl, "9nl_kernelIdLb0ELb1ELb1ELi2E") == 1, "perturbed cloudsc2_nl fp64: loop not seen"
+    assert pf["tl_kernel"] >= 16 and pf["nl_kernel"] >= 28 and pf["nl_taylor_multi_kernel"] >= 64 and pf["ad_kernel"] >= 32, pf
+    return {"tl_ring_kernel": n_tl, "nl_ring_kernel": n_nl, "register_path_prefetch_batches": pf}
 
 
 if __name__ == "__main__":

@@ -59,6 +59,12 @@ constexpr bool kADPark = ((CS2_AD_PARK) & (sizeof(T) == 8 ? 1 : 2)) != 0;
 #ifndef CS2_AD_KEEP_MB
 #define CS2_AD_KEEP_MB 0
 #endif
+#ifndef CS2_AD_DRAIN
+#define CS2_AD_DRAIN 0  // bit 0 / bit 1: drain the level's stores before the next level is requested in sweep 1 / sweep 2
+#endif
+#ifndef CS2_AD_LANDED
+#define CS2_AD_LANDED 0 // 1: aph_k marked as landed before sweep 1's loop (see landed()): sweep 1 then keeps its stores in
+#endif                  // flight across levels - measured slower (+1.0 ... +1.5 %, docs/TUNING_LOG.md 3.9)
 #ifndef CS2_AD_PIN
 #define CS2_AD_PIN 3    // fp64 constants pinned in VGPRs: bit 0 = the physical constants, bit 1 = the exp coefficients
 #endif
@@ -497,8 +503,12 @@ __device__ __forceinline__ void ad_forward(const Ext<T>& e, const NLK<T>& kc, co
 // Adjoint forcing of one level: the perturbations of the 10 NL outputs that level k feeds.
 template <typename T>
 struct ADForce {
-    T clc, tnd_q, tnd_qi, tnd_ql, tnd_t, fplsl1, fplsn1;  // flux forcings at half level k+1, already
-                                                          // combined with the enthalpy-flux ones (:481-484)
+    T clc, tnd_q, tnd_qi, tnd_ql, tnd_t;
+    // flux and enthalpy-flux forcings at half level k+1, RAW: ad_load_force is the prefetch of the NEXT level, and any
+    // arithmetic on a loaded word at the load site makes hipcc wait for it there - a full memory latency on every level
+    // (r03: `s_waitcnt vmcnt(11)` right behind the 26 loads of the batch).  ad_flux_forcing combines them (:481-484)
+    // where the level is computed.
+    T fplsl1, fplsn1, fhpsl1, fhpsn1;
     T covptot;                                            // read by the evaporation block only
 };
 
@@ -511,10 +521,19 @@ __device__ __forceinline__ ADForce<T> ad_load_force(const CPtrs<T, NL_NUM_OUT>& 
     f.tnd_qi = ldg(a.p[NL_OUT_TND_QI], o);
     f.tnd_ql = ldg(a.p[NL_OUT_TND_QL], o);
     f.tnd_t = ldg(a.p[NL_OUT_TND_T], o);
-    f.fplsl1 = ldg(a.p[NL_OUT_FPLSL], o + lsb) - ldg(a.p[NL_OUT_FHPSL], o + lsb) * e.RLVTT;
-    f.fplsn1 = ldg(a.p[NL_OUT_FPLSN], o + lsb) - ldg(a.p[NL_OUT_FHPSN], o + lsb) * e.RLSTT;
+    f.fplsl1 = ldg(a.p[NL_OUT_FPLSL], o + lsb);
+    f.fhpsl1 = ldg(a.p[NL_OUT_FHPSL], o + lsb);
+    f.fplsn1 = ldg(a.p[NL_OUT_FPLSN], o + lsb);
+    f.fhpsn1 = ldg(a.p[NL_OUT_FHPSN], o + lsb);
     f.covptot = EVAP ? ldg(a.p[NL_OUT_COVPTOT], o) : T(0.0);
     return f;
+}
+
+// :481-484: the flux forcings a level sees are in_fpls*_i - RL*TT * in_fhps*_i (formed when the level is computed).
+template <typename T>
+__device__ __forceinline__ void ad_flux_forcing(const ADForce<T>& f, const Ext<T>& e, T& fplsl1, T& fplsn1) {
+    fplsl1 = f.fplsl1 - f.fhpsl1 * e.RLVTT;
+    fplsn1 = f.fplsn1 - f.fhpsn1 * e.RLSTT;
 }
 
 template <typename T>
@@ -558,7 +577,9 @@ __device__ __forceinline__ ADOut<T> ad_backward(const Ext<T>& e, const NLK<T>& k
     ADOut<T> o;
 #if CS2_AD_DIAG == 1
     {
-        const T s2 = f.clc + f.tnd_q + f.tnd_qi + f.tnd_ql + f.tnd_t + f.fplsl1 + f.fplsn1 + r.t2 + sfl + b.tmp_rfln_i;
+        T d_fl, d_fn;
+        ad_flux_forcing<T>(f, e, d_fl, d_fn);
+        const T s2 = f.clc + f.tnd_q + f.tnd_qi + f.tnd_ql + f.tnd_t + d_fl + d_fn + r.t2 + sfl + b.tmp_rfln_i;
         o.ap = s2; o.t = s2 + T(1); o.q = s2 + T(2); o.ql = s2 + T(3); o.qi = s2 + T(4); o.qsat = s2 + T(5); o.lude = s2 + T(6);
         o.mfd = s2 + T(7); o.mfu = s2 + T(8); o.aph1 = s2 + T(9); o.lu1 = s2 + T(10);
         b.tmp_rfln_i = s2;
@@ -570,8 +591,10 @@ __device__ __forceinline__ ADOut<T> ad_backward(const Ext<T>& e, const NLK<T>& k
     const T cons2 = kc.cons2, rdt = kc.rdt;
     const T lvdcp = r.lvdcp, lsdcp = r.lsdcp, fwat = r.fwat, gdp = r.gdp;
     // :500-501
-    T tmp_rfln_i = b.tmp_rfln_i + b.rfl_i + f.fplsl1;
-    T tmp_sfln_i = b.tmp_sfln_i + b.sfl_i + f.fplsn1;
+    T f_fplsl1, f_fplsn1;
+    ad_flux_forcing<T>(f, e, f_fplsl1, f_fplsn1);
+    T tmp_rfln_i = b.tmp_rfln_i + b.rfl_i + f_fplsl1;
+    T tmp_sfln_i = b.tmp_sfln_i + b.sfl_i + f_fplsn1;
     // :504-511
     T o_qi = -f.tnd_qi * rdt;
     T qiwc_i = f.tnd_qi * rdt;
@@ -957,6 +980,7 @@ ad_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
         T aph_k = ldg(in.p[NL_IN_APH], colb);
         uint32_t o = colb;
         ADIn<T> xa = ad_load<T>(in, lsb, o, 0 >= keep_from);
+        if constexpr (CS2_AD_LANDED != 0) landed(aph_k);
         for (int k = 0; k < nz; ++k) {
             ADIn<T> xn = xa;
             const bool keep_n = k + 1 >= keep_from;   // level k+1 (and the fluxes entering it) stay cacheable
@@ -976,6 +1000,7 @@ ad_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
             stg_sel(out.p[NL_OUT_FPLSN], o + lsb, r.sfln, keep_n);
             stg(out.p[NL_OUT_FHPSL], o + lsb, -r.rfln * e.RLVTT);
             stg(out.p[NL_OUT_FHPSN], o + lsb, -r.sfln * e.RLSTT);
+            if constexpr ((CS2_AD_DRAIN & 1) != 0) drain_vmem();
             rfl = r.rfln;
             sfl = r.sfln;
             aph_k = xa.aph1;
@@ -1033,6 +1058,7 @@ ad_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
             stg(oadj.p[NL_IN_TND_CML_QI], o, dt * a.qi);
             stg(oadj.p[NL_IN_APH], o + lsb, a.aph1);
             stg(oadj.p[NL_IN_LU], o + lsb, a.lu1);
+            if constexpr ((CS2_AD_DRAIN & 2) != 0) drain_vmem();
             xa = xn;
             fa = fn;
             aph_k = aph_n;

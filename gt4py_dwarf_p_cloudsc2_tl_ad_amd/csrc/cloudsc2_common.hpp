@@ -214,6 +214,22 @@ __device__ __forceinline__ void pin_vgpr(T& x) {
     asm volatile("" : "+v"(x));
 }
 
+// "This loaded word has landed": the value must be in its register here, so hipcc waits for its load HERE.  Used on
+// words loaded before a level loop and first read inside it: a load still pending at the loop header makes hipcc's
+// wait-count insertion settle for `s_waitcnt vmcnt(0)` at the first use INSIDE the loop - on every level, i.e. the
+// prefetch of the next level is waited for in the middle of the current one (docs/TUNING_LOG.md 3.9).
+template <typename T>
+__device__ __forceinline__ void landed(T& x) {
+    asm volatile("" : "+v"(x));
+}
+
+// "Every memory operation of this wave has completed": the level's stores are drained before the next level's loads are
+// requested.  Costs the stores' completion latency once per level and buys HBM a cleaner read / write phase structure;
+// which one wins is measured per kernel (CS2_*_DRAIN switches, docs/TUNING_LOG.md 3.9).
+__device__ __forceinline__ void drain_vmem() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // Field access by 32-bit BYTE offset from a uniform base pointer: hipcc then emits the
 // `global_load_dwordx2 v, v_off, s[base:base+1]` form (no per-access 64-bit VALU address arithmetic).
 // The launchers guarantee (nz+1) * lev_stride * sizeof(T) < 2^32.

@@ -33,6 +33,10 @@
 #define CS2_NL_PINX 1   // pin the exp coefficients in VGPRs (fp64 only)
 #endif
 
+#ifndef CS2_NL_DRAIN
+#define CS2_NL_DRAIN 1   // register-path kernel: drain the level's stores before the next level is requested (see drain_vmem)
+#endif
+
 namespace cs2 {
 
 template <typename T>
@@ -401,12 +405,19 @@ nl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
     }
 
     const int gcol = xcd_block() * kColBlock + threadIdx.x;
+    // Lanes past the last column retire here.  They must not be carried along under an `if (live)` around the stores: that
+    // branch is a merge point for hipcc's wait-count insertion, which then drains every store of a level
+    // (`s_waitcnt vmcnt(0)`) before the next level's words are handed over (docs/TUNING_LOG.md 3.9).  FUSE == 3 ends in
+    // a workgroup reduction (a barrier): its dead lanes shadow the last column and add 0 to the sums; it has no stores.
+    if constexpr (FUSE != 3)
+        if (gcol >= nx) return;
 #if CS2_NL_DIAG == 2
-    const bool live = gcol < nx && nz < 0;   // never true at run time: no stores
+    const bool live = nz < 0;                // never true at run time: no stores
 #else
-    const bool live = gcol < nx;
+    constexpr bool live = true;
 #endif
-    const int col = (gcol < nx) ? gcol : nx - 1;  // dead lanes shadow the last column, stores masked
+    const double wlive = gcol < nx ? 1.0 : 0.0;
+    const int col = (gcol < nx) ? gcol : nx - 1;
 #if CS2_NL_DIAG == 2
     const uint32_t lsb = 0;                  // every level reads level 0 (cache-resident)
 #else
@@ -453,6 +464,8 @@ nl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
     NLIn<T> xa = nl_load<T, FUSE == 1>(in, lsb, colb, keepq != 0);
     NLIn<T> xia;
     if constexpr (PERT) xia = nl_load<T, false>(in_i, lsb, colb);
+    landed(c.aph_k);   // first read inside the loop: see landed()
+    if constexpr (EVAP) landed(aph_s);
     double acc[FUSE == 3 ? NL_NUM_OUT : 1] = {};
     uint32_t o = colb;  // byte offset of (level k, column)
     for (int k = 0; k < nz; ++k) {
@@ -477,20 +490,20 @@ nl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
         }
         const NLOut<T> r = nl_level<T, EVAP, LIN>(e, kc, xk, x, s_eta[k], s_scalm[k], crh, dt, aph_s, c);
         if constexpr (FUSE == 3) {
-            if (live) {
-                acc[NL_OUT_CLC] += double(r.clc - ref[NL_OUT_CLC]);
-                acc[NL_OUT_COVPTOT] += double(r.covptot - ref[NL_OUT_COVPTOT]);
-                acc[NL_OUT_TND_Q] += double(r.tnd_q - ref[NL_OUT_TND_Q]);
-                acc[NL_OUT_TND_T] += double(r.tnd_t - ref[NL_OUT_TND_T]);
-                acc[NL_OUT_TND_QL] += double(r.tnd_ql - ref[NL_OUT_TND_QL]);
-                acc[NL_OUT_TND_QI] += double(r.tnd_qi - ref[NL_OUT_TND_QI]);
-                acc[NL_OUT_FPLSL] += double(r.rfln - ref[NL_OUT_FPLSL]);
-                acc[NL_OUT_FPLSN] += double(r.sfln - ref[NL_OUT_FPLSN]);
-                acc[NL_OUT_FHPSL] += double(enthalpy_diff<T>(r.rfln, e.RLVTT, ref[NL_OUT_FHPSL]));
-                acc[NL_OUT_FHPSN] += double(enthalpy_diff<T>(r.sfln, e.RLSTT, ref[NL_OUT_FHPSN]));
-            }
+            // wlive = 1 (exact) or 0 (a lane past the last column: its shadow of column nx-1 is finite)
+            acc[NL_OUT_CLC] += wlive * double(r.clc - ref[NL_OUT_CLC]);
+            acc[NL_OUT_COVPTOT] += wlive * double(r.covptot - ref[NL_OUT_COVPTOT]);
+            acc[NL_OUT_TND_Q] += wlive * double(r.tnd_q - ref[NL_OUT_TND_Q]);
+            acc[NL_OUT_TND_T] += wlive * double(r.tnd_t - ref[NL_OUT_TND_T]);
+            acc[NL_OUT_TND_QL] += wlive * double(r.tnd_ql - ref[NL_OUT_TND_QL]);
+            acc[NL_OUT_TND_QI] += wlive * double(r.tnd_qi - ref[NL_OUT_TND_QI]);
+            acc[NL_OUT_FPLSL] += wlive * double(r.rfln - ref[NL_OUT_FPLSL]);
+            acc[NL_OUT_FPLSN] += wlive * double(r.sfln - ref[NL_OUT_FPLSN]);
+            acc[NL_OUT_FHPSL] += wlive * double(enthalpy_diff<T>(r.rfln, e.RLVTT, ref[NL_OUT_FHPSL]));
+            acc[NL_OUT_FHPSN] += wlive * double(enthalpy_diff<T>(r.sfln, e.RLSTT, ref[NL_OUT_FHPSN]));
         } else {
             if (live) nl_store<T>(out, e, lsb, o, r);
+            if constexpr (CS2_NL_DRAIN != 0) drain_vmem();
         }
         xa = xn;
         if constexpr (PERT) xia = xin;

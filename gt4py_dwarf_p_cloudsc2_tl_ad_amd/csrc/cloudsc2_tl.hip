@@ -15,6 +15,10 @@
 #define CS2_TL_DIAG 0   // diagnostics only (wrong results): 1 = the kernel's memory traffic without the physics
 #endif
 
+#ifndef CS2_TL_DRAIN
+#define CS2_TL_DRAIN 1   // register-path kernel: drain the level's stores before the next level is requested (see drain_vmem)
+#endif
+
 namespace cs2 {
 
 template <typename T>
@@ -581,10 +585,13 @@ tl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
     }
 
     const int gcol = xcd_block() * kColBlock + threadIdx.x;
-    const bool live = gcol < nx;
-    const int col = live ? gcol : nx - 1;
+    // Lanes past the last column retire here (no workgroup barrier follows build_level_table).  They must not be carried
+    // along under an `if (live)` around the stores: that branch is a merge point for hipcc's wait-count insertion, which
+    // then drains every store of a level (`s_waitcnt vmcnt(0)`) before the next level's words are handed over
+    // (docs/TUNING_LOG.md 3.9).
+    if (gcol >= nx) return;
     const uint32_t lsb = uint32_t(ls) * uint32_t(sizeof(T));
-    const uint32_t colb = uint32_t(col) * uint32_t(sizeof(T));
+    const uint32_t colb = uint32_t(gcol) * uint32_t(sizeof(T));
 
     const T trpaus = trpaus_prescan<T>(in.p[NL_IN_T], in.p[NL_IN_TND_CML_T], lsb, colb, dt, s_eta, klo, khi);
     const CrhCol<T> crh = crh_setup<T>(trpaus);
@@ -602,17 +609,15 @@ tl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
         c.aph_s_i = EVAP ? ldg(in_i.p[NL_IN_APH], uint32_t(nz) * lsb + colb) : T(0.0);
     }
 
-    if (live) {
-        // :757-765
-        stg(out.p[NL_OUT_FPLSL], colb, T(0.0));
-        stg(out_i.p[NL_OUT_FPLSL], colb, T(0.0));
-        stg(out.p[NL_OUT_FPLSN], colb, T(0.0));
-        stg(out_i.p[NL_OUT_FPLSN], colb, T(0.0));
-        stg(out.p[NL_OUT_FHPSL], colb, T(0.0));
-        stg(out_i.p[NL_OUT_FHPSL], colb, T(0.0));
-        stg(out.p[NL_OUT_FHPSN], colb, T(0.0));
-        stg(out_i.p[NL_OUT_FHPSN], colb, T(0.0));
-    }
+    // :757-765
+    stg(out.p[NL_OUT_FPLSL], colb, T(0.0));
+    stg(out_i.p[NL_OUT_FPLSL], colb, T(0.0));
+    stg(out.p[NL_OUT_FPLSN], colb, T(0.0));
+    stg(out_i.p[NL_OUT_FPLSN], colb, T(0.0));
+    stg(out.p[NL_OUT_FHPSL], colb, T(0.0));
+    stg(out_i.p[NL_OUT_FHPSL], colb, T(0.0));
+    stg(out.p[NL_OUT_FHPSN], colb, T(0.0));
+    stg(out_i.p[NL_OUT_FHPSN], colb, T(0.0));
 
     uint32_t o = colb;
     if constexpr (INC) {
@@ -622,7 +627,8 @@ tl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
             if (k + 1 < nz) xn = tl_load<T>(in, lsb, o + lsb);
             const TLIn<T> ya = tl_increment<T>(xa, finc, zero_supsat_i != 0);
             const TLOut<T> r = tl_level<T, REG, EVAP>(e, kc, xk, xa, ya, k, s_eta[k], s_scalm[k], crh, dt, c);
-            if (live) tl_store<T>(out, out_i, e, lsb, o, r);
+            tl_store<T>(out, out_i, e, lsb, o, r);
+            if constexpr (CS2_TL_DRAIN != 0) drain_vmem();
             xa = xn;
             o += lsb;
         }
@@ -635,7 +641,8 @@ tl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
                 yn = tl_load<T>(in_i, lsb, o + lsb);
             }
             const TLOut<T> r = tl_level<T, REG, EVAP>(e, kc, xk, xa, ya, k, s_eta[k], s_scalm[k], crh, dt, c);
-            if (live) tl_store<T>(out, out_i, e, lsb, o, r);
+            tl_store<T>(out, out_i, e, lsb, o, r);
+            if constexpr (CS2_TL_DRAIN != 0) drain_vmem();
             xa = xn;
             ya = yn;
             o += lsb;

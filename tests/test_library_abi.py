@@ -164,9 +164,16 @@ def test_outputs_must_not_alias_other_fields(hip_lib):
     with pytest.raises(ValueError, match="overlaps"):
         nl._check_disjoint({**good, "out_clc": good["out_covptot"]}, nx, nz + 1, nx, 8)       # two outputs, one buffer
     # two windows of one allocation: columns [0, 8) and [8, 16) with lev_stride 16 interleave but never touch
+    # (every field of a call shares ONE level stride - HipStencil._geometry refuses anything else - so the other fields
+    # of this call are windows of 2*nx-wide buffers too: judging a dense field by a stride that is not its own makes the
+    # verdict depend on where malloc happened to put it)
     big = torch.zeros((nz + 1, 2 * nx), dtype=torch.float64)
     wa, wb = storage.logical_view(big[:, :nx]), storage.logical_view(big[:, nx:])
-    nl._check_disjoint({**good, "in_t": wa, "out_tnd_t": wb}, nx, nz + 1, 2 * nx, 8)
+    wide = {n: storage.logical_view(torch.zeros((nz + 1, 2 * nx), dtype=torch.float64)[:, :nx]) for n in good}
+    nl._check_disjoint({**wide, "in_t": wa, "out_tnd_t": wb}, nx, nz + 1, 2 * nx, 8)
+    with pytest.raises(ValueError, match="overlaps"):
+        nl._check_disjoint({**wide, "in_t": wa, "out_tnd_t": storage.logical_view(big[:, nx - 1:2 * nx - 1])},
+                           nx, nz + 1, 2 * nx, 8)                                           # windows share column nx-1
     ad = compile_stencil("cloudsc2_ad", {"NLEV": nz})
     ad_fields = {**{"in_" + n: z() for n in NL_IN}, **{"in_" + n + "_i": z() for n in NL_OUT},
                  **{"out_" + n: z() for n in NL_OUT}, **{"out_" + n + "_i": z() for n in NL_IN}}

@@ -1,8 +1,10 @@
 """The hand-counted `s_waitcnt vmcnt(N)` of the LDS-ring kernels (cloudsc2_tl and the headline cloudsc2_nl) are only right
 if the compiled level loops issue exactly the operations the counts assume.  The checks themselves live beside the sources
 (gt4py_dwarf_p_cloudsc2_tl_ad_amd/csrc/check_ring_isa.py - `__graft_entry__.build()` runs them whenever it recompiles);
-this file compiles the two sources to gfx950 assembly (no GPU needed) and runs them in the CPU suite, plus two mutation
-tests showing that the NL guard really fails on a dropped store and on a foreign wait."""
+this file compiles the sources to gfx950 assembly (no GPU needed) and runs them in the CPU suite, plus mutation tests
+showing that the NL guard really fails on a dropped store and on a foreign wait.  Since r03 the same file guards the
+register-path kernels (tl_kernel, nl_kernel, nl_taylor_multi_kernel, ad_kernel): a level's prefetch must not be waited for
+at the load site (check_prefetch_distance)."""
 import os
 import sys
 
@@ -50,3 +52,34 @@ def test_nl_ring_guard_detects_a_dropped_store_and_a_foreign_wait(nl_asm):
         isa.check_nl_ring(nl_asm[:j] + "\ts_nop 0 ; " + nl_asm[j:].lstrip())           # one store of a level gone
     with pytest.raises(AssertionError):
         isa.check_nl_ring(nl_asm[:j] + "\ts_waitcnt vmcnt(5)\n" + nl_asm[j:])          # a wait hipcc added on its own
+
+
+@pytest.fixture(scope="module")
+def ad_asm(tmp_path_factory):
+    return _compile(tmp_path_factory, "cloudsc2_ad.hip")
+
+
+def test_register_path_prefetch_is_not_waited_for_at_the_load_site(tl_asm, nl_asm, ad_asm):
+    """r03: cloudsc2_ad formed its flux forcings at the load site, and hipcc answered with `s_waitcnt vmcnt(11)` ten
+    instructions behind the 26 prefetch loads of every level of sweep 2 (-2.2 ... -3.3 % once removed).  Every level loop
+    of the register-path kernels is checked on the compiled ISA: the first wait that reaches into a prefetch batch is
+    at least 60 instructions behind it."""
+    assert isa.check_prefetch_distance(tl_asm, "9tl_kernelI") == 16              # T x REG x EVAP x INC
+    assert isa.check_prefetch_distance(nl_asm, "9nl_kernelI", skip=r"Lb1ELb[01]ELb[01]ELi3E") == 28
+    assert isa.check_prefetch_distance(nl_asm, "nl_taylor_multi_kernelI") >= 64
+    assert isa.check_prefetch_distance(ad_asm, "9ad_kernelI") == 32              # T x REG x FIX x EVAP, two sweeps each
+    assert isa.check_prefetch_distance(ad_asm, "9ad_kernelIdLb1ELb0ELb0E") == 2  # the drivers' default
+
+
+def test_prefetch_guard_detects_a_wait_behind_the_loads(ad_asm):
+    """Mutation: a wait for (nearly) the whole batch, planted right behind the last prefetch load of the default AD
+    kernel's second sweep, must trip the guard."""
+    import re
+
+    k0 = ad_asm.index("_ZN3cs29ad_kernelIdLb1ELb0ELb0E")
+    k1 = ad_asm.index(".end_amdhsa_kernel", k0)
+    loads = [m.end() for m in re.finditer(r"global_load_dwordx2 [^\n]*\n", ad_asm[k0:k1])]
+    at = k0 + loads[-1]                      # the last ordinary load of the kernel: sweep 2's prefetch batch
+    mutated = ad_asm[:at] + "\ts_waitcnt vmcnt(3)\n" + ad_asm[at:]
+    with pytest.raises(AssertionError, match="waited for"):
+        isa.check_prefetch_distance(mutated, "9ad_kernelIdLb1ELb0ELb0E")

@@ -261,6 +261,30 @@ def check_prefetch_distance(asm, prefix, min_instr=60, min_batch=14, skip=None):
     return seen
 
 
+def kernel_resources(asm, key):
+    """{'NumVgprs', 'NumAgprs', 'ScratchSize', 'Occupancy'} of the one kernel whose mangled name contains `key`, from the
+    metadata comments hipcc writes behind the kernel."""
+    start = next(m.start() for m in re.finditer(r"^(_ZN3cs2\w+):", asm, flags=re.M) if key in m.group(1))
+    tail = asm[start:asm.index(".end_amdhsa_kernel", start) + 4000]
+    return {k: int(re.search(rf"; {k}: (\d+)", tail).group(1)) for k in ("NumVgprs", "NumAgprs", "ScratchSize", "Occupancy")}
+
+
+def check_resources(asm_nl, asm_tl, asm_ad) -> dict:
+    """Register budgets the launch heuristics and DESIGN's numbers rest on: no scratch in the kernels the drivers' defaults
+    run, and cloudsc2_ad fp32 at three waves per SIMD (what its LDS parking buys; r03: two more live words took it to 170
+    VGPRs = two waves without anybody noticing, until the register cap was requested)."""
+    out = {}
+    for what, asm, key in (("nl_ring f64", asm_nl, "nl_ring_kernelIdLb0ELb1ELb1ELi3ELb0ELb0E"),
+                           ("nl_ring f32", asm_nl, "nl_ring_kernelIfLb0ELb1ELb0ELi2ELb0ELb0E"),
+                           ("tl f64", asm_tl, "9tl_kernelIdLb1ELb0ELb0E"), ("tl_ring f32", asm_tl, "tl_ring_kernelIfLb1ELb0E"),
+                           ("ad f64", asm_ad, "9ad_kernelIdLb1ELb0ELb0E"), ("ad f32", asm_ad, "9ad_kernelIfLb1ELb0ELb0E")):
+        r = kernel_resources(asm, key)
+        assert r["ScratchSize"] == 0, (what, "spills to scratch", r)
+        out[what] = r
+    assert out["ad f32"]["Occupancy"] >= 3, out["ad f32"]
+    return out
+
+
 def check_all(out_dir=None) -> dict:
     """Compile both ring sources to assembly and check every instantiation; raises AssertionError on a mismatch."""
     with tempfile.TemporaryDirectory() as tmp:
@@ -280,7 +304,9 @@ def check_all(out_dir=None) -> dict:
     assert check_prefetch_distance(asm_ad, "9ad_kernelIdLb1ELb0ELb0E") == 2, "cloudsc2_ad fp64 default: two sweeps not seen"
     assert check_prefetch_distance(asm_nl, "9nl_kernelIdLb0ELb1ELb1ELi2E") == 1, "perturbed cloudsc2_nl fp64: loop not seen"
     assert pf["tl_kernel"] >= 16 and pf["nl_kernel"] >= 28 and pf["nl_taylor_multi_kernel"] >= 64 and pf["ad_kernel"] >= 32, pf
-    return {"tl_ring_kernel": n_tl, "nl_ring_kernel": n_nl, "register_path_prefetch_batches": pf}
+    res = check_resources(asm_nl, asm_tl, asm_ad)
+    return {"tl_ring_kernel": n_tl, "nl_ring_kernel": n_nl, "register_path_prefetch_batches": pf,
+            "ad_f32_occupancy": res["ad f32"]["Occupancy"]}
 
 
 if __name__ == "__main__":

@@ -934,8 +934,10 @@ __device__ __forceinline__ ADOut<T> ad_backward(const Ext<T>& e, const NLK<T>& k
     return o;
 }
 
+// fp32 without the evaporation block: three waves per SIMD (<= 168 VGPRs) is what the LDS parking was built for (+4.7 %,
+// DESIGN 3.5); r03's two extra raw forcing words took the unconstrained allocation to 170 VGPRs = two waves, so it is asked for.
 template <typename T, bool REG, bool FIX, bool EVAP>
-__global__ void __launch_bounds__(kColBlock)
+__global__ void __launch_bounds__(kColBlock, (sizeof(T) == 4 && !EVAP) ? 3 : 1)
 ad_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, NL_NUM_IN> in,
           CPtrs<T, NL_NUM_OUT> adj, const T* __restrict__ eta, MPtrs<T, NL_NUM_OUT> out, MPtrs<T, NL_NUM_IN> oadj,
           T dt, int keep_from) {

@@ -83,3 +83,9 @@ def test_prefetch_guard_detects_a_wait_behind_the_loads(ad_asm):
     mutated = ad_asm[:at] + "\ts_waitcnt vmcnt(3)\n" + ad_asm[at:]
     with pytest.raises(AssertionError, match="waited for"):
         isa.check_prefetch_distance(mutated, "9ad_kernelIdLb1ELb0ELb0E")
+
+
+def test_register_budgets_of_the_default_kernels(nl_asm, tl_asm, ad_asm):
+    """No scratch in the kernels the drivers' defaults run; cloudsc2_ad fp32 keeps three waves per SIMD."""
+    res = isa.check_resources(nl_asm, tl_asm, ad_asm)
+    assert res["ad f32"]["Occupancy"] == 3 and res["ad f64"]["NumVgprs"] <= 256

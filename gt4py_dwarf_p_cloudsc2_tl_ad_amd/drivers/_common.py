@@ -218,7 +218,7 @@ def tune_field_placement(field_dicts, objective, *, _any_device: bool = False, *
     np_dtype = {torch.float64: np.float64, torch.float32: np.float32}[first.dtype]
     try:
         fields, report = storage.tune_placement(nx, nz, np_dtype, first.device, order, sources, launch, **tuner_kw)
-    except Exception as exc:  # noqa: BLE001 - e.g. out of memory, "do not fit 60 % of the free device memory", a failing objective
+    except Exception as exc:  # noqa: BLE001 - e.g. out of memory, "do not fit the arena cap", a failing objective
         # the state must not be left pointing into a half-tuned arena with its inout fields modified by candidate runs:
         # every DataArray goes back to its original storage with its original contents, and the caller runs untuned
         for g, olds, n in zip(groups, originals, order):

@@ -132,7 +132,8 @@ def plan_placement_grid(n: int, slab: int, free_bytes: Optional[int], *, spacing
     max_arena_bytes = min(max_arena_bytes, free_cap)        # never ask for more than 60 % of what is free now
     fit = [e for e in spacings if n * (slab + e * two_mb) + two_mb <= max_arena_bytes]
     if not fit:
-        raise RuntimeError(f"tune_placement: {n} fields of {slab} B do not fit 60 % of the free device memory")
+        raise RuntimeError(f"tune_placement: {n} fields of {slab} B do not fit the arena cap of {max_arena_bytes} B "
+                           "(min(max_arena_bytes, 60 % of the free device memory))")
     spacings = tuple(fit)
     emax = max(spacings)
     span = n * (slab + emax * two_mb) + two_mb

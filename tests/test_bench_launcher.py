@@ -85,7 +85,7 @@ def test_every_rank_sizes_its_placement_arena_against_its_own_device(monkeypatch
         grid, need, _ = storage.plan_placement_grid(26, slab, int(free), **kw)
         assert need <= 0.6 * free and need <= 40 << 30 and len(grid) >= 2, (free, need)
         assert need >= 26 * slab                                   # and it does hold the 26 fields
-    with pytest.raises(RuntimeError, match="do not fit 60 %"):
+    with pytest.raises(RuntimeError, match="do not fit the arena cap"):
         storage.plan_placement_grid(26, slab, int(2e9), **kw)
     asked = []
 
@@ -94,7 +94,7 @@ def test_every_rank_sizes_its_placement_arena_against_its_own_device(monkeypatch
         return (int(2e9), int(288e9))                              # almost nothing free on that device
 
     monkeypatch.setattr(torch.cuda, "mem_get_info", fake_mem_get_info)
-    with pytest.raises(RuntimeError, match="do not fit 60 %"):     # refused BEFORE anything is allocated
+    with pytest.raises(RuntimeError, match="do not fit the arena cap"):     # refused BEFORE anything is allocated
         storage.tune_placement(65536, 137, np.float64, torch.device("cuda", 5), ["f%d" % i for i in range(26)], {}, None)
     assert asked == [torch.device("cuda", 5)]
     src = open(BENCH).read()

@@ -123,7 +123,7 @@ def test_a_failing_tuner_leaves_the_callers_state_untouched(monkeypatch, capsys)
         scratch = {n: storage.logical_view(sources[n].clone()) for n in order}
         launch(scratch)                                         # the DataArrays now point into `scratch`
         assert state["f_a"].data.data_ptr() == scratch[order[0]].data_ptr()
-        raise RuntimeError("tune_placement: 3 fields of 2097152 B do not fit 60 % of the free device memory")
+        raise RuntimeError("tune_placement: 3 fields of 2097152 B do not fit the arena cap of 1048576 B")
 
     monkeypatch.setattr(storage, "tune_placement", failing_tuner)
     rep = _common.tune_field_placement([state, diags], objective, _any_device=True)

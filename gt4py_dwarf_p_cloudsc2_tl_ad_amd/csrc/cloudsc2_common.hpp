@@ -226,8 +226,9 @@ __device__ __forceinline__ void landed(T& x) {
 // "Every memory operation of this wave has completed": the level's stores are drained before the next level's loads are
 // requested.  Costs the stores' completion latency once per level and buys HBM a cleaner read / write phase structure;
 // which one wins is measured per kernel (CS2_*_DRAIN switches, docs/TUNING_LOG.md 3.9).
+template <int LEFT = 0>   // LEFT: how many of the youngest operations may stay in flight (0 = a full drain)
 __device__ __forceinline__ void drain_vmem() {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LEFT) : "memory");
 }
 
 // Field access by 32-bit BYTE offset from a uniform base pointer: hipcc then emits the

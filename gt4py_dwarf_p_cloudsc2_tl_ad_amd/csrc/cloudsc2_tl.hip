@@ -15,6 +15,9 @@
 #define CS2_TL_DIAG 0   // diagnostics only (wrong results): 1 = the kernel's memory traffic without the physics
 #endif
 
+#ifndef CS2_TL_DRAIN_LEFT
+#define CS2_TL_DRAIN_LEFT 0   // stores that may stay in flight at the drain: 0 / 5 / 10 / 15 / all = 694.8 / 697.7 / 706.1 / 714.1 / 717.5 us
+#endif
 #ifndef CS2_TL_DRAIN
 #define CS2_TL_DRAIN 1   // register-path kernel: drain the level's stores before the next level is requested (see drain_vmem)
 #endif
@@ -628,7 +631,7 @@ tl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
             const TLIn<T> ya = tl_increment<T>(xa, finc, zero_supsat_i != 0);
             const TLOut<T> r = tl_level<T, REG, EVAP>(e, kc, xk, xa, ya, k, s_eta[k], s_scalm[k], crh, dt, c);
             tl_store<T>(out, out_i, e, lsb, o, r);
-            if constexpr (CS2_TL_DRAIN != 0) drain_vmem();
+            if constexpr (CS2_TL_DRAIN != 0) drain_vmem<CS2_TL_DRAIN_LEFT>();
             xa = xn;
             o += lsb;
         }
@@ -642,7 +645,7 @@ tl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
             }
             const TLOut<T> r = tl_level<T, REG, EVAP>(e, kc, xk, xa, ya, k, s_eta[k], s_scalm[k], crh, dt, c);
             tl_store<T>(out, out_i, e, lsb, o, r);
-            if constexpr (CS2_TL_DRAIN != 0) drain_vmem();
+            if constexpr (CS2_TL_DRAIN != 0) drain_vmem<CS2_TL_DRAIN_LEFT>();
             xa = xn;
             ya = yn;
             o += lsb;

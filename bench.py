@@ -1029,7 +1029,11 @@ def main(argv=None):
             res["default_placement_is_value"] = True
         if default_placement is not None:
             # rank 0's figure on separate allocations, scaled to the job (weak scaling: every rank does the same work)
-            if "value_this_rank" in default_placement:
+            if "value_this_rank" in default_placement and rehearsal and dist is not None:
+                # ranks sharing ONE GPU: rank 0 timed this window while the others were already done - not a job figure
+                res["value_default_placement"] = None
+                res["default_placement_note"] = "not taken in a rehearsal (ranks share one GPU)"
+            elif "value_this_rank" in default_placement:
                 res["value_default_placement"] = default_placement["value_this_rank"] * world
                 res["ms_per_step_default_placement"] = default_placement["ms_per_step"]
             else:

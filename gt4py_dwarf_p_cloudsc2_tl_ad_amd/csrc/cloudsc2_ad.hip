@@ -964,7 +964,11 @@ ad_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
     T* const park_lds = s_scalm + (nz + 1) + threadIdx.x;
     (void)park_lds;
     if (gcol >= nx) return;  // no later workgroup barrier: whole lanes may retire
+#if CS2_AD_DIAG == 2
+    const uint32_t lsb = nz < 0 ? uint32_t(ls) : 0u;   // diagnostics only (wrong results): every level reads and writes level 0 -
+#else                                                  // cache-resident rows, the kernel's time without HBM
     const uint32_t lsb = uint32_t(ls) * uint32_t(sizeof(T));
+#endif
     const uint32_t colb = uint32_t(gcol) * uint32_t(sizeof(T));
 
     const T trpaus = trpaus_prescan<T>(in.p[NL_IN_T], in.p[NL_IN_TND_CML_T], lsb, colb, dt, s_eta, klo, khi);

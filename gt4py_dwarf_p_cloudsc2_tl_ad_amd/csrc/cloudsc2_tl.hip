@@ -593,7 +593,11 @@ tl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
     // then drains every store of a level (`s_waitcnt vmcnt(0)`) before the next level's words are handed over
     // (docs/TUNING_LOG.md 3.9).
     if (gcol >= nx) return;
+#if CS2_TL_DIAG == 2
+    const uint32_t lsb = nz < 0 ? uint32_t(ls) : 0u;   // diagnostics only (wrong results): every level reads and writes level 0 -
+#else                                                  // cache-resident rows, the kernel's time without HBM
     const uint32_t lsb = uint32_t(ls) * uint32_t(sizeof(T));
+#endif
     const uint32_t colb = uint32_t(gcol) * uint32_t(sizeof(T));
 
     const T trpaus = trpaus_prescan<T>(in.p[NL_IN_T], in.p[NL_IN_TND_CML_T], lsb, colb, dt, s_eta, klo, khi);

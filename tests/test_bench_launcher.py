@@ -189,6 +189,13 @@ def test_bench_line_carries_the_contract_on_the_gpu(gpu):
     assert pc["passed"] and pc["points_outside_tolerance"] == 0 and pc["columns"] == 256 and pc["fields"] == 11
     assert 0 <= pc["max_err_over_field_scale"] < 1e-10
     assert d["fused_step"]["results_equal_unfused"] is True
+    # the tuner's winner was held against plain allocations before the timed region, in the headline and in every leg, and
+    # the record says which one was timed; the untuned figure stands beside `value`
+    for rep in (d["placement"], d["roofline_tl"]["placement"], d["roofline_ad"]["placement"], d["roofline_nl_f32"]["placement"]):
+        assert rep["chosen"].startswith(("tuned arena", "plain allocations")), rep
+        assert rep["recheck_tuned_ms"] > 0 and rep["recheck_plain_ms"] > 0
+        assert (rep["mode"] == "separate") == rep["chosen"].startswith("plain")
+    assert d["value_default_placement"] > 1e7
 
 
 @pytest.mark.gpu

@@ -150,7 +150,8 @@ def tune_placement(nx: int, nz: int, dtype: Any, device: Any, order, sources, la
                    staggers=(FieldArena.STAGGER, 8448), shifts_mb=(0, 4096, 8192, 12288), wide_spacings=(),
                    wide_shifts_mb=tuple(range(0, 32769, 2048)), launches: int = 5, rounds: int = 3,
                    budget_s: float = 4.0, max_arena_bytes: int = 40 << 30, max_shift_spans: float = 4.0,
-                   keep_all: bool = False):
+                   keep_all: bool = False, extend_shifts_mb=(16384, 20480, 24576, 28672), extend_below_gain: float = 0.04,
+                   extend_min_span_bytes: int = 1 << 30):
     """Calibrate WHERE the fields of a stencil call sit in HBM, for this process.
 
     The rate at which a call streams its 26-72 fields depends on how their starting addresses relate (channel, bank and
@@ -170,6 +171,13 @@ def tune_placement(nx: int, nz: int, dtype: Any, device: Any, order, sources, la
     offset on some leases (placements that straddle such a boundary with their last few fields beyond it run the NL
     kernel 4-8 % faster, profiles/r02/placement_structure.txt) and a wide placement meets a boundary more often than a
     narrow one - but over fresh processes it did not find faster placements than the narrow grid (same file, A/B).
+
+    Second stage (r03): the fast placements of an arena are the ones whose last fields lie beyond a junction of the arena's
+    physical backing, and on some leases the first junction is ~28-32 GB into the arena (profiles/r02/placement_structure.txt,
+    scans 1 and 2: fast shifts at 28, 29 | 60, 61 | ... GB) - out of reach of shifts 0-12 GB.  When the first stage gains less
+    than `extend_below_gain` over the default placement, a second arena is searched at `extend_shifts_mb` (same budget
+    again), the two winners are timed against each other, and the loser's arena is freed.  A lease that needs it pays
+    ~4 s and a 33-39 GB arena instead of 18-24 GB; a lease that does not, nothing.
 
     Returns (fields at the fastest placement - inputs copied in, outputs zeroed; a report dict).  The arena stays alive
     as long as the returned fields do (up to `max_arena_bytes` and never more than 60 % of the free device memory:
@@ -272,6 +280,30 @@ def tune_placement(nx: int, nz: int, dtype: Any, device: Any, order, sources, la
               "second_pass": [(round(c[0], 4), c[1], c[2], c[3] >> 20) for c in finals]}
     if keep_all:                 # every first-pass timing (profiles/placement_distribution.py)
         report["first_pass_all"] = [(round(c[0], 4), c[1], c[2], c[3] >> 20) for c in results]
+    # (only for placements that span >= 1 GB: small fields live in the caches, and a 30 GB arena for them would be absurd)
+    if extend_shifts_mb and n * slab >= extend_min_span_bytes and t_best2 > (1.0 - extend_below_gain) * t_default2:
+        try:
+            fields2, report2 = tune_placement(
+                nx, nz, dtype, device, order, {k: (klayout(fields[k]) if sources.get(k) is not None else None) for k in order},
+                launch, spacings=spacings, staggers=staggers, shifts_mb=tuple(extend_shifts_mb), wide_spacings=(),
+                launches=launches, rounds=rounds, budget_s=budget_s, max_arena_bytes=max_arena_bytes, max_shift_spans=1e9,
+                extend_shifts_mb=())
+        except RuntimeError as exc:          # no room for the bigger arena: the first stage stands
+            report["second_stage"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+            return fields, report
+        t1, t2 = timed(fields), timed(fields2)
+        stage = {"tuned_ms": report2["tuned_ms"], "retimed_first_ms": t1, "retimed_second_ms": t2,
+                 "shift_MB": report2["shift_MB"], "extra_spacing_x2MB": report2["extra_spacing_x2MB"],
+                 "candidates": report2["candidates"], "arena_bytes": report2["arena_bytes"]}
+        if t2 < t1:
+            report2.update(default_ms=t_default2, first_stage={"tuned_ms": t_best2, "shift_MB": report["shift_MB"],
+                                                                "extra_spacing_x2MB": report["extra_spacing_x2MB"]},
+                           second_stage=dict(stage, chosen=True), tuned_ms=t2,
+                           candidates=report["candidates"] + report2["candidates"])
+            del fields, buf, warm, finals
+            return fields2, report2
+        report["second_stage"] = dict(stage, chosen=False)
+        del fields2
     return fields, report
 
 

@@ -70,6 +70,20 @@ def test_tuned_placement_is_bit_identical_and_reports_what_it_did(gpu):
     for n in NL_OUT:
         assert torch.equal(tuned["out_" + n], sep["out_" + n]), n
     assert torch.equal(tuned["in_qsat"], sep["in_qsat"])
+    # the second stage (a second arena searched at shifts further out when the first gained too little), forced here
+    # at a small size: whichever stage wins, the fields it returns hold the inputs and compute the same results
+    tuned2, rep2 = storage.tune_placement(nx, nz, np.float64, gpu, order, sources, step, spacings=(0, 1), staggers=(2304,),
+                                          budget_s=0.3, extend_shifts_mb=(64, 128), extend_below_gain=1.0,
+                                          extend_min_span_bytes=0)
+    st2 = rep2["second_stage"]
+    assert st2["candidates"] >= 2 and st2["shift_MB"] in (0, 64, 128) and isinstance(st2["chosen"], bool)
+    assert ("first_stage" in rep2) == st2["chosen"] and rep2["tuned_ms"] > 0
+    for k, src in sources.items():
+        assert torch.equal(storage.klayout(tuned2[k]), src), k
+    step(tuned2)
+    torch.cuda.synchronize()
+    for n in NL_OUT:
+        assert torch.equal(tuned2["out_" + n], sep["out_" + n]), n
 
 
 @pytest.mark.gpu

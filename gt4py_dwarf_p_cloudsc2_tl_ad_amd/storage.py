@@ -281,11 +281,14 @@ def tune_placement(nx: int, nz: int, dtype: Any, device: Any, order, sources, la
     if keep_all:                 # every first-pass timing (profiles/placement_distribution.py)
         report["first_pass_all"] = [(round(c[0], 4), c[1], c[2], c[3] >> 20) for c in results]
     # (only for placements that span >= 1 GB: small fields live in the caches, and a 30 GB arena for them would be absurd)
-    if extend_shifts_mb and n * slab >= extend_min_span_bytes and t_best2 > (1.0 - extend_below_gain) * t_default2:
+    free_now = torch.cuda.mem_get_info(dev)[0] if dev.type == "cuda" else 0
+    room = min(max_arena_bytes, int(0.6 * free_now)) if dev.type == "cuda" else 0
+    reachable = [sh for sh in extend_shifts_mb if (int(sh) << 20) + n * slab + two_mb <= room]
+    if reachable and n * slab >= extend_min_span_bytes and t_best2 > (1.0 - extend_below_gain) * t_default2:
         try:
             fields2, report2 = tune_placement(
                 nx, nz, dtype, device, order, {k: (klayout(fields[k]) if sources.get(k) is not None else None) for k in order},
-                launch, spacings=spacings, staggers=staggers, shifts_mb=tuple(extend_shifts_mb), wide_spacings=(),
+                launch, spacings=spacings, staggers=staggers, shifts_mb=tuple(reachable), wide_spacings=(),
                 launches=launches, rounds=rounds, budget_s=budget_s, max_arena_bytes=max_arena_bytes, max_shift_spans=1e9,
                 extend_shifts_mb=())
         except RuntimeError as exc:          # no room for the bigger arena: the first stage stands

@@ -93,6 +93,11 @@ def parse_args(argv=None):
     ap.add_argument("--precision", choices=["double", "single"], default=None)
     ap.add_argument("--cpu-cols", type=int, default=16384,
                     help="columns of the CPU-baseline sample (0 disables the baseline)")
+    ap.add_argument("--cpu-budget-s", type=float, default=8.0,
+                    help="seconds the C/OpenMP CPU-baseline loop runs for (the NumPy leg gets 0.75 x, the all-cores leg 0.5 x)")
+    ap.add_argument("--startup-budget-s", type=float, default=120.0,
+                    help="a rank that needed longer than this to get from process start to the placement tuner skips the tuner "
+                         "(plain allocations; the record says so): keeps an N-rank run on a cold node inside the driver's clock")
     ap.add_argument("--no-roofline-events", action="store_true")
     ap.add_argument("--no-extra-rooflines", action="store_true",
                     help="skip the TL / AD / fp32-NL kernel legs (N = 1 only)")
@@ -163,6 +168,22 @@ def launch_ranks(args, argv) -> int:
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
+def host_cpu_share():
+    """(cores in this process's affinity mask, CPU quota of its cgroup in cores or None): what "the node's host cores" are
+    for THIS process.  A container may show every core of the node in the mask and still be throttled to a quota."""
+    aff = len(os.sched_getaffinity(0))
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            with open(path) as fh:
+                q, per = fh.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(per)
+        except (OSError, ValueError):
+            pass
+    return aff, quota
+
+
 def cpu_baseline(cols: int, nz: int, np_dtype, budget_s: float = 8.0, hip_step=None):
     """CPU baselines on the host, saturation + cloudsc2_nl on `cols` synthetic columns (BASELINE configs[0] size):
       * headline `value`: the plain-C + OpenMP restatement (oracle/cloudsc2_nl_omp.c, SURVEY 8d "restatement B")
@@ -197,14 +218,16 @@ def cpu_baseline(cols: int, nz: int, np_dtype, budget_s: float = 8.0, hip_step=N
         oracle.saturation(fields["in_ap"], fields["in_t"], fields["in_qsat"], ext)
         run_oracle_nl(fields, eta, dt, ext)
 
-    n_runs, n_el = loop(numpy_step, 6.0)
+    n_runs, n_el = loop(numpy_step, 0.75 * budget_s)
     numpy_rate = cols * n_runs / n_el
     what = f"saturation + cloudsc2_nl, {cols} cols x {nz} lev"
-    res = {"unit": "columns/s", "host_cores": os.cpu_count(), "kind": "port",
+    aff, quota = host_cpu_share()
+    res = {"unit": "columns/s", "host_cores": os.cpu_count(), "affinity_cores": aff, "cgroup_cpu_quota_cores": quota,
+           "kind": "port", "rank": int(os.environ.get("RANK", "0")), "world_size": int(os.environ.get("WORLD_SIZE", "1")),
            "numpy_1core": {"value": numpy_rate, "unit": "columns/s", "cores": 1,
                            "sample": f"NumPy restatement, {what} {np.dtype(np_dtype).name}, {n_runs} runs in {n_el:.1f} s"}}
     try:
-        threads = min(len(os.sched_getaffinity(0)), 16)
+        threads = max(1, min(aff, 16 if quota is None else int(quota + 0.5)))
         F = {k: np.ascontiguousarray(v, dtype=np.float64) for k, v in fields.items()}
         for n in NL_OUT:
             F["out_" + n] = np.zeros_like(F["in_ap"])
@@ -229,19 +252,23 @@ def cpu_baseline(cols: int, nz: int, np_dtype, budget_s: float = 8.0, hip_step=N
                                    "max_err_over_field_scale": worst, "rtol": tol["rtol"], "atol_rel": tol["atol_rel"],
                                    "passed": bad == 0,
                                    "what": "HIP saturation + cloudsc2_nl against oracle/cloudsc2_nl_omp.c on the same columns"}
-        # the same restatement on EVERY core this process may run on (north_star: "the node's host cores"), bounded too
-        all_threads = len(os.sched_getaffinity(0))
-        if all_threads > threads:
+        # the same restatement on EVERY core of the affinity mask (north_star: "the node's host cores") - only where the mask
+        # is not known to exceed the cgroup's CPU quota: one thread per core of a mask the process is throttled below
+        # measures the throttle, not the cores (r03: 53 k columns/s on "256 threads" of a 16-core share)
+        all_threads = aff
+        if all_threads > threads and quota is None:
             def c_step_all():
                 cloudsc2_c.saturation(F["in_ap"], F["in_t"], F["in_qsat"], ext, nthreads=all_threads)
                 cloudsc2_c.cloudsc2_nl(F, eta, dt, ext, nthreads=all_threads)
 
-            a_runs, a_el = loop(c_step_all, 4.0)
+            a_runs, a_el = loop(c_step_all, 0.5 * budget_s)
             res["all_cores"] = {"value": cols * a_runs / a_el, "unit": "columns/s", "cores": all_threads,
                                 "sample": f"same restatement and columns with one thread per core of this process's affinity "
-                                          f"mask ({all_threads}), {a_runs} runs in {a_el:.1f} s; on the builder's pool a box's "
-                                          "CPU share is 16 cores whatever the mask says, so this figure is oversubscribed "
-                                          "there - it is what the node's host cores give THIS process, as north_star asks"}
+                                          f"mask ({all_threads}; no cgroup CPU quota visible), {a_runs} runs in {a_el:.1f} s"}
+        elif all_threads > threads:
+            res["all_cores"] = {"value": None, "cores": all_threads,
+                                "sample": f"not taken: the affinity mask shows {all_threads} cores but the cgroup's CPU quota is "
+                                          f"{quota:.1f} cores - `value` ({threads} threads) is what the host gives this process"}
         res.update(value=cols * c_runs / c_el, cores=threads,
                    sample=f"plain-C + OpenMP restatement (oracle/cloudsc2_nl_omp.c, {threads} threads, scalar libm, "
                           f"-O2), {what} float64, {c_runs} runs in {c_el:.1f} s, synthetic-parameters")
@@ -263,6 +290,34 @@ class _StdoutToStderr:
         sys.stdout.flush()
         os.dup2(self._saved, 1)
         os.close(self._saved)
+
+
+def gather_rank_reports(dist, world, report):
+    """every rank's own outcome (placement chosen, start-up times, kernel time) in rank order: a rank that fell back to plain
+    allocations or skipped the tuner must be readable in the record, not guessed from a straggler in `per_rank_ms`"""
+    if dist is None:
+        return [report]
+    out = [None] * world
+    dist.all_gather_object(out, report)
+    return out
+
+
+def rank0_then_everyone(dist, rank, work, key="bench/rank0_done", timeout_s=900):
+    """`work()` on rank 0 while the other ranks WAIT without spinning (blocked on the rendezvous store's socket, not in a
+    collective: an RCCL barrier would burn a host core per waiting rank and disturb the CPU baseline being timed)."""
+    res = work() if rank == 0 else None
+    if dist is not None:
+        import datetime
+
+        from torch.distributed import distributed_c10d as c10d
+
+        store = c10d._get_default_store()
+        if rank == 0:
+            store.set(key, "1")
+        else:
+            store.wait([key], datetime.timedelta(seconds=timeout_s))
+        dist.barrier()      # everyone is here within milliseconds; the store's host may now go away
+    return res
 
 
 # ------------------------------------------------------------------------------------------------ PMC traffic
@@ -356,14 +411,29 @@ def dry_run(args, rank, world):
         dist.all_reduce(per_rank, op=dist.ReduceOp.SUM)  # the gather of the per-rank times (main() does the same)
         tm = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-    if rank == 0:
+    # the same end-of-run protocol as main(): every rank's report gathered in rank order, then the CPU baseline on rank 0
+    # while the other ranks wait on the rendezvous store
+    mine = {"rank": rank, "device": None, "mode": "dry run", "chosen": "none (no kernels)", "ms_per_step": 1.0 * (rank + 1),
+            "nl_kernel_ms": None, "startup_s": {"to_first_step_s": 0.0}}
+    rank_reports = gather_rank_reports(dist if dist.is_initialized() else None, world, mine)
+
+    def rank0_record():
         res = base_record(args, world, nx, nz, value=None, ms_per_step=None,
                           ranks=dist.get_world_size() if dist.is_initialized() else None, backend="gloo (dry run)")
         res["per_rank_ms"] = [1e3 * float(x) for x in per_rank]
         res["per_rank_ms_min_max"] = [min(res["per_rank_ms"]), max(res["per_rank_ms"])]
+        res["per_rank_placement"] = rank_reports
         res.update(dry_run=True, data="dry run: no kernels were launched",
                    shard_check={"col0_sum": float(t[1]), "eta_sum_x_world": float(t[2]), "eta_sum": float(first[2])})
+        wsize = 8 if args.precision == "double" else 4
+        res["roofline"] = {"kernel": None, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+                           "traffic": None, "bytes_per_launch": NL_WORDS_PER_COL * wsize * nx, "columns": nx,
+                           "note": "dry run: no kernel was launched; the object's shape is what main() fills in"}
+        if args.cpu_cols > 0:
+            res["cpu_baseline"] = cpu_baseline(args.cpu_cols, nz, np.float64, budget_s=args.cpu_budget_s)
         print(json.dumps(res), flush=True)
+
+    rank0_then_everyone(dist if dist.is_initialized() else None, rank, rank0_record)
     if dist.is_initialized():
         dist.destroy_process_group()
 
@@ -608,12 +678,16 @@ def main(argv=None):
     if args.config in (3, 4):
         return harness_bench(args, rank, local_rank, world)
 
+    t_start = time.perf_counter()
     import numpy as np
     import torch
 
     import __graft_entry__ as ge
 
+    startup = {"import_s": time.perf_counter() - t_start}
+    t1 = time.perf_counter()
     ge.build()
+    startup["build_s"] = time.perf_counter() - t1
     from gt4py_dwarf_p_cloudsc2_tl_ad_amd import _lib, storage
     from gt4py_dwarf_p_cloudsc2_tl_ad_amd.params import DEFAULT_TIMESTEP_S, default_externals
     from gt4py_dwarf_p_cloudsc2_tl_ad_amd.stencils import INC, NL_IN, NL_OUT, compile_stencil
@@ -651,7 +725,10 @@ def main(argv=None):
     last_kernel = lambda: _lib.last_kernel()  # noqa: E731
 
     # resident state: this rank's slice [rank*nx, (rank+1)*nx) of the global problem
+    t1 = time.perf_counter()
     s = make_resident_state(total, nz, rank * nx, nx, np_dtype, device)
+    torch.cuda.synchronize()
+    startup["state_s"] = time.perf_counter() - t1
     eta = torch.as_tensor(eta_levels(nz, dtype=np_dtype), device=device)  # from GLOBAL column 0
     sat = compile_stencil("saturation", ext)
     _nl = compile_stencil("cloudsc2_nl", ext)
@@ -715,7 +792,10 @@ def main(argv=None):
     sources = {"in_" + k[2:]: v for k, v in s.items()}
     placement = {"mode": args.placement}
     F = None
-    if args.placement == "tuned":
+    if args.placement == "tuned" and time.perf_counter() - t_start > args.startup_budget_s:
+        placement = {"mode": "separate", "tune_skipped": f"start-up took {time.perf_counter() - t_start:.0f} s before the tuner "
+                                                         f"(> --startup-budget-s {args.startup_budget_s:.0f})"}
+    elif args.placement == "tuned":
         try:
             tkw = {}
             if args.tune_shifts_mb:      # dev A/B of the shift range: explicit, validated (was an environment switch)
@@ -739,6 +819,11 @@ def main(argv=None):
         F.update({"out_" + n: storage.zeros(nx, nz, np_dtype, device) for n in NL_OUT})
         storage.set_arena_capacity(old_cap)
     del s, sources
+    startup["tune_s"] = placement.get("tuning_s", 0.0)
+    startup["to_first_step_s"] = time.perf_counter() - t_start
+    print(f"[bench] rank {rank}: import {startup['import_s']:.1f} s, build {startup['build_s']:.1f} s, state "
+          f"{startup['state_s']:.1f} s, placement {startup['tune_s']:.1f} s ({placement.get('chosen', placement['mode'])}); "
+          f"{startup['to_first_step_s']:.1f} s from process start to the first step", file=sys.stderr, flush=True)
     ins = {k: v for k, v in F.items() if k.startswith("in_")}
     outs = {k: v for k, v in F.items() if k.startswith("out_")}
     qsat = F["in_qsat"]
@@ -1009,8 +1094,15 @@ def main(argv=None):
         norm = norm.to(red_device)
         dist.all_reduce(norm, op=dist.ReduceOp.SUM)
     norm = [float(x) for x in norm.cpu()]
+    mine = {"rank": rank, "device": f"cuda:{local_rank}", "ms_per_step": per_rank_ms[rank] if dist is not None else per_rank_ms[0],
+            "nl_kernel_ms": nl_ms, "startup_s": startup}
+    mine.update({k: placement[k] for k in ("mode", "chosen", "arena_GB", "tuning_s", "tuned_ms", "default_ms", "recheck_tuned_ms",
+                                            "recheck_plain_ms", "tune_error", "tune_skipped", "recheck_error") if k in placement})
+    mine.setdefault("chosen", {"separate": "plain allocations", "arena": "default arena"}.get(placement["mode"], placement["mode"])
+                    + (" (tuner failed or skipped)" if "tune_error" in placement or "tune_skipped" in placement else " (as requested)"))
+    rank_reports = gather_rank_reports(dist, world, mine)
 
-    if rank == 0:
+    def rank0_record():
         res = base_record(args, world, nx, nz, value=total * args.steps / elapsed,
                           ms_per_step=1e3 * elapsed / args.steps,
                           ranks=dist.get_world_size() if dist is not None else None,
@@ -1022,6 +1114,10 @@ def main(argv=None):
         res["per_rank_ms"] = per_rank_ms
         res["per_rank_ms_min_max"] = [min(per_rank_ms), max(per_rank_ms)]
         res["placement"] = placement
+        # every rank's own placement outcome, start-up times and kernel time, in rank order (rank 0's `placement` above is
+        # the full report of ONE rank; a rank that skipped the tuner or fell back to plain allocations shows here)
+        res["per_rank_placement"] = rank_reports
+        res["startup_s_max_over_ranks"] = max(r["startup_s"]["to_first_step_s"] for r in rank_reports)
         if default_placement is None and placement.get("chosen", "").startswith("plain"):
             # the timed region itself ran on plain allocations (they beat the tuner's winner): the two figures coincide
             res["value_default_placement"] = res["value"]
@@ -1048,7 +1144,9 @@ def main(argv=None):
         res.update(extra)
         if fused is not None:
             res["fused_step"] = fused
-        if world == 1 and args.cpu_cols > 0:
+        if args.cpu_cols > 0:
+            # the CPU baseline beside the GPU figure at EVERY world size (north_star: "in the same run"), on rank 0, after
+            # the closing barrier and every reduction; the other ranks wait in rank0_then_everyone without spinning
             def hip_step(Fh, eta_h, dt_h):
                 """saturation + cloudsc2_nl through the stencil objects on host fields in [k][col] layout (fp64)"""
                 n_c = Fh["in_ap"].shape[1]
@@ -1066,9 +1164,12 @@ def main(argv=None):
                 got["qsat"] = storage.klayout(D["in_qsat"]).cpu().numpy()
                 return got
 
-            res["cpu_baseline"] = cpu_baseline(args.cpu_cols, nz, np.float64,
-                                               hip_step=hip_step)
+            budget = args.cpu_budget_s if time.perf_counter() - t_start < 200.0 else min(args.cpu_budget_s, 3.0)
+            res["cpu_baseline"] = cpu_baseline(args.cpu_cols, nz, np.float64, budget_s=budget, hip_step=hip_step)
+        res["wall_s_rank0"] = time.perf_counter() - t_start
         print(json.dumps(res), flush=True)
+
+    rank0_then_everyone(dist, rank, rank0_record)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -32,9 +32,29 @@ CSRC = os.path.dirname(os.path.abspath(__file__))
 HIPCC = "/opt/rocm/bin/hipcc"
 
 
+def compile_flags(src: str):
+    """the flags the Makefile compiles `src` with (`make -n -B <object>`): the check must read the code generation that
+    ships, per-file switches included (cloudsc2_tl / cloudsc2_ad are built with -fno-slp-vectorize)"""
+    obj = os.path.splitext(src)[0] + ".o"
+    p = subprocess.run(["make", "-n", "-B", obj], cwd=CSRC, check=True, capture_output=True, text=True)
+    line = next(l for l in p.stdout.splitlines() if " -c " in l and src in l)
+    words = line.split()
+    flags, skip = [], False
+    for w in words[1:]:
+        if skip:
+            skip = False
+        elif w in ("-c", src):
+            continue
+        elif w == "-o":
+            skip = True
+        elif w not in ("-fPIC",):
+            flags.append(w)
+    return flags
+
+
 def compile_to_asm(src: str, out_dir: str) -> str:
     out = os.path.join(out_dir, src + ".s")
-    subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S", src, "-o", out],
+    subprocess.run([HIPCC] + compile_flags(src) + ["--cuda-device-only", "-S", src, "-o", out],
                    cwd=CSRC, check=True, capture_output=True)
     with open(out) as fh:
         return fh.read()
@@ -181,6 +201,9 @@ def check_nl_ring(asm):
         ni = 8 if t == "d" else 4
         nstore = 10
         nfull, nhead = (rd - 1) * ni + (rd - 2) * nstore, (rd - 1) * ni
+        if ragged:
+            nfull = nhead       # the ragged instantiations count no stores at all: their wait is independent of how the
+                                # exec-masked stores of a level were lowered
         nodes = _cfg(lines, execz_never_taken=ragged)
         steady = [n for n, nd in nodes.items() if nd["wait"] == nfull and nd["ring_wait"]]
         assert steady, (name, f"no s_waitcnt vmcnt({nfull})")
@@ -195,6 +218,7 @@ def check_nl_ring(asm):
                 # live lane would skip (s_cbranch_execz / execnz in several shapes) - and such a wave has retired at the
                 # top of the kernel.  So only the maximum is held statically (all masked regions entered = every store of
                 # the level issued); the aligned instantiations above pin the exact count of the same source.
+                # (since r04 the ragged wait does not depend on this count; it is still pinned as a description of the code)
                 assert r["st"][1] == want_st, (name, "stores per level (ragged)", r)
             else:
                 assert r["st"] == (want_st, want_st), (name, "stores per level", r)
@@ -285,6 +309,42 @@ def check_resources(asm_nl, asm_tl, asm_ad) -> dict:
     return out
 
 
+_ASM_VMEM = re.compile(r"^\s*((?:global|flat|buffer|scratch)_(?:load|store|atomic)\w*)\s+(.*?)\s*(?:;.*)?$")
+
+
+def check_inline_asm_vmem(asm: str, where: str = "") -> int:
+    """Every vector-memory instruction that comes from an INLINE-ASM block (hipcc brackets those with `;;#ASMSTART` /
+    `;;#ASMEND` in its -S output) must address memory as `v_off, s[base:base+1]`: a single 32-bit VGPR byte offset plus the
+    field's base pointer in an SGPR pair.  Round 3 lost a GPU (memory access fault on 0x4000 / 0xa000 = the byte offset of
+    a workgroup's first column, i.e. an address WITHOUT its base, docs/TUNING_LOG.md 3.10) to a hand-written
+    `global_store_dwordx2 ... sc1` whose ISA text nobody had read.  Compiler-generated accesses are not judged here (hipcc
+    legitimately uses the `v[a:b], off` form with a full 64-bit per-lane address); `flat_*`, `buffer_*` and `scratch_*`
+    have no business in these kernels' asm at all.  Returns the number of inline-asm memory instructions seen (all well
+    formed); raises AssertionError on the first one that is not."""
+    n, inside = 0, False
+    for ln, line in enumerate(asm.split("\n"), 1):
+        s = line.strip()
+        if s.startswith(";;#ASMSTART"):
+            inside = True
+        elif s.startswith(";;#ASMEND"):
+            inside = False
+        elif inside:
+            m = _ASM_VMEM.match(s)
+            if not m:
+                continue
+            op, operands = m.group(1), [x.strip() for x in m.group(2).split(",")]
+            ok = op.startswith("global_") and len(operands) >= 3
+            if ok:
+                # global_load*  vdst, vaddr, saddr [mods]   /   global_store*  vaddr, vdata, saddr [mods]
+                vaddr = operands[1] if op.startswith(("global_load", "global_atomic")) else operands[0]
+                saddr = operands[2].split()[0]
+                ok = re.fullmatch(r"v\d+", vaddr) is not None and re.fullmatch(r"s\[\d+:\d+\]", saddr) is not None
+            assert ok, (f"{where}:{ln}: inline-asm memory instruction `{s}` does not use the `v_off, s[base:base+1]` form - "
+                        "read profiles/README.md (rule on hand-written memory instructions) before this goes to a GPU")
+            n += 1
+    return n
+
+
 def check_all(out_dir=None) -> dict:
     """Compile both ring sources to assembly and check every instantiation; raises AssertionError on a mismatch."""
     with tempfile.TemporaryDirectory() as tmp:
@@ -305,8 +365,10 @@ def check_all(out_dir=None) -> dict:
     assert check_prefetch_distance(asm_nl, "9nl_kernelIdLb0ELb1ELb1ELi2E") == 1, "perturbed cloudsc2_nl fp64: loop not seen"
     assert pf["tl_kernel"] >= 16 and pf["nl_kernel"] >= 28 and pf["nl_taylor_multi_kernel"] >= 64 and pf["ad_kernel"] >= 32, pf
     res = check_resources(asm_nl, asm_tl, asm_ad)
+    n_asm = sum(check_inline_asm_vmem(a, f) for a, f in ((asm_nl, "cloudsc2_nl.hip"), (asm_tl, "cloudsc2_tl.hip"),
+                                                         (asm_ad, "cloudsc2_ad.hip")))
     return {"tl_ring_kernel": n_tl, "nl_ring_kernel": n_nl, "register_path_prefetch_batches": pf,
-            "ad_f32_occupancy": res["ad f32"]["Occupancy"]}
+            "ad_f32_occupancy": res["ad f32"]["Occupancy"], "inline_asm_vmem": n_asm}
 
 
 if __name__ == "__main__":

@@ -78,44 +78,44 @@ struct ADIn {
 
 // `keep`: wave-uniform; the level's 16 words are loaded with the default cache policy instead of non-temporally
 // (CS2_AD_KEEP_MB below: the levels where sweep 1 ends are the levels where sweep 2 starts).
-template <typename T>
-__device__ __forceinline__ ADIn<T> ad_load(const CPtrs<T, NL_NUM_IN>& in, uint32_t lsb, uint32_t o, bool keep = false) {
+template <typename T, typename FP>
+__device__ __forceinline__ ADIn<T> ad_load(const FP& F, uint32_t lsb, uint32_t o, bool keep = false) {
     ADIn<T> x;
     if (keep) {
-        x.ap = ldg_keep(in.p[NL_IN_AP], o);
-        x.aph1 = ldg_keep(in.p[NL_IN_APH], o + lsb);
-        x.lu1 = ldg_keep(in.p[NL_IN_LU], o + lsb);
-        x.lude = ldg_keep(in.p[NL_IN_LUDE], o);
-        x.mfd = ldg_keep(in.p[NL_IN_MFD], o);
-        x.mfu = ldg_keep(in.p[NL_IN_MFU], o);
-        x.q = ldg_keep(in.p[NL_IN_Q], o);
-        x.qi = ldg_keep(in.p[NL_IN_QI], o);
-        x.ql = ldg_keep(in.p[NL_IN_QL], o);
-        x.qsat = ldg_keep(in.p[NL_IN_QSAT], o);
-        x.supsat = ldg_keep(in.p[NL_IN_SUPSAT], o);
-        x.t = ldg_keep(in.p[NL_IN_T], o);
-        x.tq = ldg_keep(in.p[NL_IN_TND_CML_Q], o);
-        x.tqi = ldg_keep(in.p[NL_IN_TND_CML_QI], o);
-        x.tql = ldg_keep(in.p[NL_IN_TND_CML_QL], o);
-        x.tt = ldg_keep(in.p[NL_IN_TND_CML_T], o);
+        x.ap = ldg_keep(F.in(NL_IN_AP), o);
+        x.aph1 = ldg_keep(F.in(NL_IN_APH), o + lsb);
+        x.lu1 = ldg_keep(F.in(NL_IN_LU), o + lsb);
+        x.lude = ldg_keep(F.in(NL_IN_LUDE), o);
+        x.mfd = ldg_keep(F.in(NL_IN_MFD), o);
+        x.mfu = ldg_keep(F.in(NL_IN_MFU), o);
+        x.q = ldg_keep(F.in(NL_IN_Q), o);
+        x.qi = ldg_keep(F.in(NL_IN_QI), o);
+        x.ql = ldg_keep(F.in(NL_IN_QL), o);
+        x.qsat = ldg_keep(F.in(NL_IN_QSAT), o);
+        x.supsat = ldg_keep(F.in(NL_IN_SUPSAT), o);
+        x.t = ldg_keep(F.in(NL_IN_T), o);
+        x.tq = ldg_keep(F.in(NL_IN_TND_CML_Q), o);
+        x.tqi = ldg_keep(F.in(NL_IN_TND_CML_QI), o);
+        x.tql = ldg_keep(F.in(NL_IN_TND_CML_QL), o);
+        x.tt = ldg_keep(F.in(NL_IN_TND_CML_T), o);
         return x;
     }
-    x.ap = ldg(in.p[NL_IN_AP], o);
-    x.aph1 = ldg(in.p[NL_IN_APH], o + lsb);
-    x.lu1 = ldg(in.p[NL_IN_LU], o + lsb);
-    x.lude = ldg(in.p[NL_IN_LUDE], o);
-    x.mfd = ldg(in.p[NL_IN_MFD], o);
-    x.mfu = ldg(in.p[NL_IN_MFU], o);
-    x.q = ldg(in.p[NL_IN_Q], o);
-    x.qi = ldg(in.p[NL_IN_QI], o);
-    x.ql = ldg(in.p[NL_IN_QL], o);
-    x.qsat = ldg(in.p[NL_IN_QSAT], o);
-    x.supsat = ldg(in.p[NL_IN_SUPSAT], o);
-    x.t = ldg(in.p[NL_IN_T], o);
-    x.tq = ldg(in.p[NL_IN_TND_CML_Q], o);
-    x.tqi = ldg(in.p[NL_IN_TND_CML_QI], o);
-    x.tql = ldg(in.p[NL_IN_TND_CML_QL], o);
-    x.tt = ldg(in.p[NL_IN_TND_CML_T], o);
+    x.ap = ldg(F.in(NL_IN_AP), o);
+    x.aph1 = ldg(F.in(NL_IN_APH), o + lsb);
+    x.lu1 = ldg(F.in(NL_IN_LU), o + lsb);
+    x.lude = ldg(F.in(NL_IN_LUDE), o);
+    x.mfd = ldg(F.in(NL_IN_MFD), o);
+    x.mfu = ldg(F.in(NL_IN_MFU), o);
+    x.q = ldg(F.in(NL_IN_Q), o);
+    x.qi = ldg(F.in(NL_IN_QI), o);
+    x.ql = ldg(F.in(NL_IN_QL), o);
+    x.qsat = ldg(F.in(NL_IN_QSAT), o);
+    x.supsat = ldg(F.in(NL_IN_SUPSAT), o);
+    x.t = ldg(F.in(NL_IN_T), o);
+    x.tq = ldg(F.in(NL_IN_TND_CML_Q), o);
+    x.tqi = ldg(F.in(NL_IN_TND_CML_QI), o);
+    x.tql = ldg(F.in(NL_IN_TND_CML_QL), o);
+    x.tt = ldg(F.in(NL_IN_TND_CML_T), o);
     return x;
 }
 // store / load with the cache policy chosen by a wave-uniform flag (sweep 1's fluxes that sweep 2 reads back)
@@ -512,20 +512,19 @@ struct ADForce {
     T covptot;                                            // read by the evaporation block only
 };
 
-template <typename T, bool EVAP>
-__device__ __forceinline__ ADForce<T> ad_load_force(const CPtrs<T, NL_NUM_OUT>& a, const Ext<T>& e, uint32_t lsb,
-                                                    uint32_t o) {
+template <typename T, bool EVAP, typename FP>
+__device__ __forceinline__ ADForce<T> ad_load_force(const FP& F, const Ext<T>& e, uint32_t lsb, uint32_t o) {
     ADForce<T> f;
-    f.clc = ldg(a.p[NL_OUT_CLC], o);
-    f.tnd_q = ldg(a.p[NL_OUT_TND_Q], o);
-    f.tnd_qi = ldg(a.p[NL_OUT_TND_QI], o);
-    f.tnd_ql = ldg(a.p[NL_OUT_TND_QL], o);
-    f.tnd_t = ldg(a.p[NL_OUT_TND_T], o);
-    f.fplsl1 = ldg(a.p[NL_OUT_FPLSL], o + lsb);
-    f.fhpsl1 = ldg(a.p[NL_OUT_FHPSL], o + lsb);
-    f.fplsn1 = ldg(a.p[NL_OUT_FPLSN], o + lsb);
-    f.fhpsn1 = ldg(a.p[NL_OUT_FHPSN], o + lsb);
-    f.covptot = EVAP ? ldg(a.p[NL_OUT_COVPTOT], o) : T(0.0);
+    f.clc = ldg(F.adj(NL_OUT_CLC), o);
+    f.tnd_q = ldg(F.adj(NL_OUT_TND_Q), o);
+    f.tnd_qi = ldg(F.adj(NL_OUT_TND_QI), o);
+    f.tnd_ql = ldg(F.adj(NL_OUT_TND_QL), o);
+    f.tnd_t = ldg(F.adj(NL_OUT_TND_T), o);
+    f.fplsl1 = ldg(F.adj(NL_OUT_FPLSL), o + lsb);
+    f.fhpsl1 = ldg(F.adj(NL_OUT_FHPSL), o + lsb);
+    f.fplsn1 = ldg(F.adj(NL_OUT_FPLSN), o + lsb);
+    f.fhpsn1 = ldg(F.adj(NL_OUT_FHPSN), o + lsb);
+    f.covptot = EVAP ? ldg(F.adj(NL_OUT_COVPTOT), o) : T(0.0);
     return f;
 }
 
@@ -934,13 +933,50 @@ __device__ __forceinline__ ADOut<T> ad_backward(const Ext<T>& e, const NLK<T>& k
     return o;
 }
 
+// Kernel arguments as ONE struct (kernarg offset 0): the field pointers are fetched from the kernarg segment at their
+// point of use (KernArgs in cloudsc2_common.hpp) instead of living in - and being spilled from - SGPRs.
+template <typename T>
+struct ADArgs {
+    Ext<T> e;
+    NLK<T> kc;
+    ExpK<T> xk;
+    int nx, nz;
+    int64_t ls;
+    CPtrs<T, NL_NUM_IN> in;
+    CPtrs<T, NL_NUM_OUT> adj;
+    const T* eta;
+    MPtrs<T, NL_NUM_OUT> out;
+    MPtrs<T, NL_NUM_IN> oadj;
+    T dt;
+    int keep_from;
+};
+#ifndef CS2_AD_KARG
+#define CS2_AD_KARG 1   // 1: field pointers are re-read from the kernarg segment (scalar loads) on every level
+#endif
+template <typename T>
+struct ADFields : KernArgs<ADArgs<T>> {
+    __device__ __forceinline__ void fresh() { KernArgs<ADArgs<T>>::template fresh<(CS2_AD_KARG != 0)>(); }
+    __device__ __forceinline__ const T* in(int i) const { return this->ka->in.p[i]; }
+    __device__ __forceinline__ const T* adj(int i) const { return this->ka->adj.p[i]; }
+    __device__ __forceinline__ T* out(int i) const { return this->ka->out.p[i]; }
+    __device__ __forceinline__ const T* outc(int i) const { return this->ka->out.p[i]; }
+    __device__ __forceinline__ T* oadj(int i) const { return this->ka->oadj.p[i]; }
+    __device__ __forceinline__ const T* oadjc(int i) const { return this->ka->oadj.p[i]; }
+};
+
 // fp32 without the evaporation block: three waves per SIMD (<= 168 VGPRs) is what the LDS parking was built for (+4.7 %,
 // DESIGN 3.5); r03's two extra raw forcing words took the unconstrained allocation to 170 VGPRs = two waves, so it is asked for.
 template <typename T, bool REG, bool FIX, bool EVAP>
 __global__ void __launch_bounds__(kColBlock, (sizeof(T) == 4 && !EVAP) ? 3 : 1)
-ad_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, NL_NUM_IN> in,
-          CPtrs<T, NL_NUM_OUT> adj, const T* __restrict__ eta, MPtrs<T, NL_NUM_OUT> out, MPtrs<T, NL_NUM_IN> oadj,
-          T dt, int keep_from) {
+ad_kernel(const ADArgs<T> A) {
+    Ext<T> e = A.e;
+    NLK<T> kc = A.kc;
+    ExpK<T> xk = A.xk;
+    const int nx = A.nx, nz = A.nz, keep_from = A.keep_from;
+    const int64_t ls = A.ls;
+    const T* __restrict__ eta = A.eta;
+    T dt = A.dt;
+    ADFields<T> F;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     T* s_eta = reinterpret_cast<T*>(smem_raw);
     T* s_scalm = s_eta + (nz + 1);
@@ -971,41 +1007,42 @@ ad_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
 #endif
     const uint32_t colb = uint32_t(gcol) * uint32_t(sizeof(T));
 
-    const T trpaus = trpaus_prescan<T>(in.p[NL_IN_T], in.p[NL_IN_TND_CML_T], lsb, colb, dt, s_eta, klo, khi);
+    const T trpaus = trpaus_prescan<T>(F.in(NL_IN_T), F.in(NL_IN_TND_CML_T), lsb, colb, dt, s_eta, klo, khi);
     const CrhCol<T> crh = crh_setup<T>(trpaus);
 
     // ---------------- sweep 1: trajectory + NL outputs (:146-475)
-    stg(out.p[NL_OUT_FPLSL], colb, T(0.0));
-    stg(out.p[NL_OUT_FPLSN], colb, T(0.0));
-    stg(out.p[NL_OUT_FHPSL], colb, T(0.0));
-    stg(out.p[NL_OUT_FHPSN], colb, T(0.0));
-    const T aph_s = EVAP ? ldg(in.p[NL_IN_APH], uint32_t(nz) * lsb + colb) : T(1.0);
-    T* const park = oadj.p[NL_IN_MFD];  // EVAP: level k holds the cover entering level k until sweep 2 overwrites it
+    stg(F.out(NL_OUT_FPLSL), colb, T(0.0));
+    stg(F.out(NL_OUT_FPLSN), colb, T(0.0));
+    stg(F.out(NL_OUT_FHPSL), colb, T(0.0));
+    stg(F.out(NL_OUT_FHPSN), colb, T(0.0));
+    const T aph_s = EVAP ? ldg(F.in(NL_IN_APH), uint32_t(nz) * lsb + colb) : T(1.0);
+    #define park F.oadj(NL_IN_MFD)  // EVAP: level k holds the cover entering level k until sweep 2 overwrites it
     {
         T rfl = T(0.0), sfl = T(0.0), covptot = T(0.0);
-        T aph_k = ldg(in.p[NL_IN_APH], colb);
+        T aph_k = ldg(F.in(NL_IN_APH), colb);
         uint32_t o = colb;
-        ADIn<T> xa = ad_load<T>(in, lsb, o, 0 >= keep_from);
+        ADIn<T> xa = ad_load<T>(F, lsb, o, 0 >= keep_from);
         if constexpr (CS2_AD_LANDED != 0) landed(aph_k);
         for (int k = 0; k < nz; ++k) {
+            F.fresh();
             ADIn<T> xn = xa;
             const bool keep_n = k + 1 >= keep_from;   // level k+1 (and the fluxes entering it) stay cacheable
-            if (k + 1 < nz) xn = ad_load<T>(in, lsb, o + lsb, keep_n);
+            if (k + 1 < nz) xn = ad_load<T>(F, lsb, o + lsb, keep_n);
             ADTraj<T> r;
             ad_forward<T, FIX, EVAP>(e, kc, xk, xa, aph_k, k, s_eta[k], s_scalm[k], crh, dt, rfl, sfl, covptot, aph_s,
                                      r);
             if constexpr (EVAP) stg(park, o, covptot);
             covptot = r.covptot;
-            stg(out.p[NL_OUT_CLC], o, r.out_clc);
-            stg(out.p[NL_OUT_COVPTOT], o, r.out_covptot);
-            stg(out.p[NL_OUT_TND_Q], o, r.tnd_q);
-            stg(out.p[NL_OUT_TND_T], o, r.tnd_t);
-            stg(out.p[NL_OUT_TND_QL], o, r.tnd_ql);
-            stg(out.p[NL_OUT_TND_QI], o, r.tnd_qi);
-            stg_sel(out.p[NL_OUT_FPLSL], o + lsb, r.rfln, keep_n);
-            stg_sel(out.p[NL_OUT_FPLSN], o + lsb, r.sfln, keep_n);
-            stg(out.p[NL_OUT_FHPSL], o + lsb, -r.rfln * e.RLVTT);
-            stg(out.p[NL_OUT_FHPSN], o + lsb, -r.sfln * e.RLSTT);
+            stg(F.out(NL_OUT_CLC), o, r.out_clc);
+            stg(F.out(NL_OUT_COVPTOT), o, r.out_covptot);
+            stg(F.out(NL_OUT_TND_Q), o, r.tnd_q);
+            stg(F.out(NL_OUT_TND_T), o, r.tnd_t);
+            stg(F.out(NL_OUT_TND_QL), o, r.tnd_ql);
+            stg(F.out(NL_OUT_TND_QI), o, r.tnd_qi);
+            stg_sel(F.out(NL_OUT_FPLSL), o + lsb, r.rfln, keep_n);
+            stg_sel(F.out(NL_OUT_FPLSN), o + lsb, r.sfln, keep_n);
+            stg(F.out(NL_OUT_FHPSL), o + lsb, -r.rfln * e.RLVTT);
+            stg(F.out(NL_OUT_FHPSN), o + lsb, -r.sfln * e.RLSTT);
             if constexpr ((CS2_AD_DRAIN & 1) != 0) drain_vmem();
             rfl = r.rfln;
             sfl = r.sfln;
@@ -1023,47 +1060,48 @@ ad_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
     {
         int k = nz - 1;
         uint32_t o = uint32_t(k) * lsb + colb;
-        ADIn<T> xa = ad_load<T>(in, lsb, o, k >= keep_from);
-        ADForce<T> fa = ad_load_force<T, EVAP>(adj, e, lsb, o);
-        T aph_k = ldg_sel(in.p[NL_IN_APH], o, k >= keep_from);
-        T sfl = ldg_sel(const_cast<const T*>(out.p[NL_OUT_FPLSN]), o, k >= keep_from);
-        T rfl = ldg_sel(const_cast<const T*>(out.p[NL_OUT_FPLSL]), o, k >= keep_from);
-        T cov = EVAP ? ldg(const_cast<const T*>(park), o) : T(0.0);
+        ADIn<T> xa = ad_load<T>(F, lsb, o, k >= keep_from);
+        ADForce<T> fa = ad_load_force<T, EVAP>(F, e, lsb, o);
+        T aph_k = ldg_sel(F.in(NL_IN_APH), o, k >= keep_from);
+        T sfl = ldg_sel(F.outc(NL_OUT_FPLSN), o, k >= keep_from);
+        T rfl = ldg_sel(F.outc(NL_OUT_FPLSL), o, k >= keep_from);
+        T cov = EVAP ? ldg(F.oadjc(NL_IN_MFD), o) : T(0.0);
         for (; k >= 0; --k) {
+            F.fresh();
             ADIn<T> xn = xa;
             ADForce<T> fn = fa;
             T aph_n = aph_k, sfl_n = sfl, rfl_n = rfl, cov_n = cov;
             if (k > 0) {
                 const uint32_t om = o - lsb;
                 const bool keep_m = k - 1 >= keep_from;
-                xn = ad_load<T>(in, lsb, om, keep_m);
+                xn = ad_load<T>(F, lsb, om, keep_m);
                 xn.aph1 = aph_k;   // aph[k]: already here as this level's upper half level (the load above is dropped)
-                fn = ad_load_force<T, EVAP>(adj, e, lsb, om);
-                aph_n = ldg_sel(in.p[NL_IN_APH], om, keep_m);
-                sfl_n = ldg_sel(const_cast<const T*>(out.p[NL_OUT_FPLSN]), om, keep_m);
-                rfl_n = ldg_sel(const_cast<const T*>(out.p[NL_OUT_FPLSL]), om, keep_m);
-                if constexpr (EVAP) cov_n = ldg(const_cast<const T*>(park), om);
+                fn = ad_load_force<T, EVAP>(F, e, lsb, om);
+                aph_n = ldg_sel(F.in(NL_IN_APH), om, keep_m);
+                sfl_n = ldg_sel(F.outc(NL_OUT_FPLSN), om, keep_m);
+                rfl_n = ldg_sel(F.outc(NL_OUT_FPLSL), om, keep_m);
+                if constexpr (EVAP) cov_n = ldg(F.oadjc(NL_IN_MFD), om);
             }
             ADTraj<T> r;
             ad_forward<T, FIX, EVAP>(e, kc, xk, xa, aph_k, k, s_eta[k], s_scalm[k], crh, dt, rfl, sfl, cov, aph_s, r);
             if constexpr (kADPark<T>) ad_park<T>(park_lds, r);
             const ADOut<T> a = ad_backward<T, REG, FIX, EVAP>(e, kc, xa, k, s_scalm[k], dt, sfl, r, fa, b, park_lds);
-            stg(oadj.p[NL_IN_AP], o, a.ap);
-            stg(oadj.p[NL_IN_T], o, a.t);
-            stg(oadj.p[NL_IN_Q], o, a.q);
-            stg(oadj.p[NL_IN_QL], o, a.ql);
-            stg(oadj.p[NL_IN_QI], o, a.qi);
-            stg(oadj.p[NL_IN_QSAT], o, a.qsat);
-            stg(oadj.p[NL_IN_LUDE], o, a.lude);
-            stg(oadj.p[NL_IN_MFD], o, a.mfd);
-            stg(oadj.p[NL_IN_MFU], o, a.mfu);
-            stg(oadj.p[NL_IN_SUPSAT], o, dt * a.q);           // :992 (Q7, literal)
-            stg(oadj.p[NL_IN_TND_CML_T], o, dt * a.t);        // :993-996
-            stg(oadj.p[NL_IN_TND_CML_Q], o, dt * a.q);
-            stg(oadj.p[NL_IN_TND_CML_QL], o, dt * a.ql);
-            stg(oadj.p[NL_IN_TND_CML_QI], o, dt * a.qi);
-            stg(oadj.p[NL_IN_APH], o + lsb, a.aph1);
-            stg(oadj.p[NL_IN_LU], o + lsb, a.lu1);
+            stg(F.oadj(NL_IN_AP), o, a.ap);
+            stg(F.oadj(NL_IN_T), o, a.t);
+            stg(F.oadj(NL_IN_Q), o, a.q);
+            stg(F.oadj(NL_IN_QL), o, a.ql);
+            stg(F.oadj(NL_IN_QI), o, a.qi);
+            stg(F.oadj(NL_IN_QSAT), o, a.qsat);
+            stg(F.oadj(NL_IN_LUDE), o, a.lude);
+            stg(F.oadj(NL_IN_MFD), o, a.mfd);
+            stg(F.oadj(NL_IN_MFU), o, a.mfu);
+            stg(F.oadj(NL_IN_SUPSAT), o, dt * a.q);           // :992 (Q7, literal)
+            stg(F.oadj(NL_IN_TND_CML_T), o, dt * a.t);        // :993-996
+            stg(F.oadj(NL_IN_TND_CML_Q), o, dt * a.q);
+            stg(F.oadj(NL_IN_TND_CML_QL), o, dt * a.ql);
+            stg(F.oadj(NL_IN_TND_CML_QI), o, dt * a.qi);
+            stg(F.oadj(NL_IN_APH), o + lsb, a.aph1);
+            stg(F.oadj(NL_IN_LU), o + lsb, a.lu1);
             if constexpr ((CS2_AD_DRAIN & 2) != 0) drain_vmem();
             xa = xn;
             fa = fn;
@@ -1076,11 +1114,12 @@ ad_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
     }
     if constexpr (EVAP) {  // :970-971: out_aph_i[nz] also receives the accumulated tmp_aph_s_i
         const uint32_t on = uint32_t(nz) * lsb + colb;
-        stg(oadj.p[NL_IN_APH], on, ldg(const_cast<const T*>(oadj.p[NL_IN_APH]), on) + b.aph_s_i);
+        stg(F.oadj(NL_IN_APH), on, ldg(F.oadjc(NL_IN_APH), on) + b.aph_s_i);
     }
     // :982-986 top half level
-    stg(oadj.p[NL_IN_APH], colb, b.daph_i - b.dp_i);
-    stg(oadj.p[NL_IN_LU], colb, T(0.0));
+    stg(F.oadj(NL_IN_APH), colb, b.daph_i - b.dp_i);
+    stg(F.oadj(NL_IN_LU), colb, T(0.0));
+#undef park
 }
 
 template <typename T>
@@ -1113,6 +1152,7 @@ int launch_ad(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
         const int levels = int((uint64_t(CS2_AD_KEEP_MB) << 20) / (per_level ? per_level : 1));
         keep_from = levels >= nz ? 0 : nz - levels;
     }
+    const ADArgs<T> args = {e, kc, xk, nx, nz, ls, ci, ca, eta, co, coa, tdt, keep_from};
 #define CS2_AD_LAUNCH(R, F, E)                                                                                         \
     do {                                                                                                               \
         auto kern = ad_kernel<T, R, F, E>;                                                                             \
@@ -1120,7 +1160,7 @@ int launch_ad(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
             static std::atomic<size_t> attr_set[kMaxDevices] = {};                                                     \
             if (!lds_opt_in(kern, attr_set, dev, smem)) return -1;                                                     \
         }                                                                                                              \
-        hipLaunchKernelGGL(kern, grid, block, smem, stream, e, kc, xk, nx, nz, ls, ci, ca, eta, co, coa, tdt, keep_from);         \
+        hipLaunchKernelGGL(kern, grid, block, smem, stream, args);         \
     } while (0)
 #define CS2_AD_LAUNCH_E(R, F) \
     do {                      \

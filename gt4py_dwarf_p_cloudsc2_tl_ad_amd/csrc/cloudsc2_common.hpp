@@ -301,6 +301,28 @@ struct CPtrs { const T* p[N]; };
 template <typename T, int N>
 struct MPtrs { T* p[N]; };
 
+// Field pointers fetched from the KERNARG SEGMENT at their point of use (cloudsc2_ad).  The AD kernel takes 52 field
+// pointers: 104 SGPRs, more than a wave has (102), before the first constant.  Passed as ordinary by-value arguments they
+// are all preloaded at kernel entry, and hipcc spills the excess to VGPR lanes and restores each with two v_readlane_b32 -
+// VALU issue slots - per memory instruction: 290 of the 1 800 VALU instructions of a cloudsc2_ad level in fp32, 396 of
+// 2 386 in fp64 (r04, counted on the ISA).  With the arguments as ONE struct (kernarg offset 0) and this view, a pointer is
+// read with a scalar load (s_load_dwordx16: SMEM, no VALU slot) right before the loads / stores that use it and its SGPRs
+// are free again afterwards.  `fresh()` makes the compiler forget what it knows about the kernarg pointer, so the scalar
+// loads behind `K->...` cannot be hoisted above that point (out of the level loop and back into long-lived SGPRs): call
+// it once per level.  Worth -2 ... -4 % on cloudsc2_ad fp32 and 0 ... -1.6 % in fp64 (the kernels wait for HBM, not for
+// issue slots: docs/TUNING_LOG.md 3.11); the same change on cloudsc2_tl measured +0.7 % and was not kept.
+template <typename ARGS>
+struct KernArgs {
+    typedef const __attribute__((address_space(4))) ARGS KA;
+    KA* ka;
+    __device__ __forceinline__ KernArgs() : ka((KA*)__builtin_amdgcn_kernarg_segment_ptr()) {}
+    template <bool ON = true>
+    __device__ __forceinline__ void fresh() {
+        if constexpr (ON) asm volatile("" : "+s"(ka));
+    }
+    __device__ __forceinline__ KA* operator->() const { return ka; }
+};
+
 // diagnostics: the launchers record the name of the kernel they enqueued (cloudsc2_last_kernel(), thread-local)
 void note_kernel(const char* name);
 

@@ -807,7 +807,9 @@ nl_ring_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtr
         const uint32_t tc = uint32_t(klo + k < nz ? klo + k : nz) * uint32_t(sizeof(T));
         if (!more) ring_read<0>(a, ta, ta + tb_off, tc, x, eta_k, scalm_k, ps_t, ps_tt, eta_ps);   // tail: drain
         else if (k < RD - 1) ring_read<NHEAD>(a, ta, ta + tb_off, tc, x, eta_k, scalm_k, ps_t, ps_tt, eta_ps);
-        else ring_read<NFULL>(a, ta, ta + tb_off, tc, x, eta_k, scalm_k, ps_t, ps_tt, eta_ps);
+        // RAGGED: the level's stores are exec-masked (`if (live)`), so their COUNT is not something the wait may rely on -
+        // the steady state counts none (the NHEAD wait: every store of earlier levels retired).  Not the headline path.
+        else ring_read<(RAGGED ? NHEAD : NFULL)>(a, ta, ta + tb_off, tc, x, eta_k, scalm_k, ps_t, ps_tt, eta_ps);
         if (k < nps_dma) {            // pre-scan of level klo + k (:107-111); the slot holds level klo + k + 1
             const T tk1 = ps_t + dt * ps_tt;
             if (eta_ps > T(0.1) && eta_ps < T(0.4) && tk_ps > tk1) trpaus = eta_ps;

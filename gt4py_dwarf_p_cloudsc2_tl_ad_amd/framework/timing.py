@@ -22,6 +22,17 @@ def _gpu() -> bool:
     return torch.cuda.is_available()
 
 
+_ENABLED = True
+
+
+def set_enabled(on: bool) -> bool:
+    """Switch the brackets off (they become no-ops) / on again; returns the previous setting.  Used by internal objectives
+    that call bracketed code hundreds of times without ever asking for the times (storage.tune_placement)."""
+    global _ENABLED
+    was, _ENABLED = _ENABLED, bool(on)
+    return was
+
+
 class Timer:
     times: Dict[str, float] = {}
     _pending: List[Tuple[str, float, object, object]] = []      # label, host seconds, start event, end event
@@ -53,6 +64,11 @@ class Timer:
 
 @contextlib.contextmanager
 def timing(label: str):
+    """A bracket's time is max(host wall time, device time between its events): per-label sums can exceed the run's wall time
+    when brackets overlap on the device (the reference reports host wall time around synchronous work)."""
+    if not _ENABLED:
+        yield Timer
+        return
     if not _gpu():                                               # CPU-only process: the host clock is the whole story
         t0 = time.perf_counter()
         try:

@@ -12,6 +12,30 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = os.path.join(ROOT, "bench.py")
 
 
+DRY = ("--dry-run", "--cpu-cols", "256", "--cpu-budget-s", "0.2")     # the CPU-baseline leg runs, on a sample of a fraction of a second
+
+
+def _nrank_record_is_complete(d, world, real_kernels):
+    """an N > 1 line carries everything the N = 1 line does - `cpu_baseline` (rank 0, after the closing
+    barrier), `roofline`, every rank's own placement outcome, and which collective backend joined how many ranks."""
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["rank"] == 0 and cb["world_size"] == world
+    assert cb["affinity_cores"] >= cb["cores"] and "cgroup_cpu_quota_cores" in cb and cb["numpy_1core"]["cores"] == 1
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and r["bytes_per_launch"] > 0
+    reps = d["per_rank_placement"]
+    assert [x["rank"] for x in reps] == list(range(world))
+    for x in reps:
+        assert "mode" in x and "chosen" in x and "startup_s" in x and x["ms_per_step"] > 0, x
+    assert len(d["per_rank_ms"]) == world
+    if real_kernels:
+        assert r["frac"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["kernel"].startswith("cs2::")
+        assert cb["parity_check"]["passed"] is True
+        assert all(x["nl_kernel_ms"] > 0 and x["startup_s"]["to_first_step_s"] > 0 for x in reps)
+        assert d["startup_s_max_over_ranks"] >= max(x["startup_s"]["to_first_step_s"] for x in reps) - 1e-9
+    assert (d["rccl_ranks"] == world) != (d.get("rehearsal_ranks") == world)        # exactly one of the two says N
+
+
 def _run(*args, env=None):
     e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     e.update(env or {})
@@ -20,11 +44,12 @@ def _run(*args, env=None):
 
 
 def test_plain_invocation_with_two_gpus_starts_two_ranks():
-    p = _run("--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run")
+    p = _run("--gpus", "2", "--steps", "3", "--warmup", "1", *DRY)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, p.stdout                       # ONE JSON line on stdout, everything else on stderr
     d = json.loads(lines[0])
+    _nrank_record_is_complete(d, 2, real_kernels=False)
     assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["steps"] == 3 and d["warmup"] == 1
     assert d["scaling"] == "weak" and d["dtype"] == "f64" and d["dry_run"] is True and d["value"] is None
     assert d["config"]["columns_per_gpu"] == 65536 and d["config"]["columns_total"] == 131072
@@ -35,13 +60,13 @@ def test_plain_invocation_with_two_gpus_starts_two_ranks():
 
 
 def test_config5_is_the_fixed_fp32_problem_split_over_the_gpus():
-    p = _run("--gpus", "2", "--config", "5", "--dry-run")
+    p = _run("--gpus", "2", "--config", "5", *DRY)
     assert p.returncode == 0, p.stderr[-3000:]
     d = json.loads(p.stdout.strip().splitlines()[-1])
     assert d["scaling"] == "strong" and d["dtype"] == "f32" and d["n_gpus"] == 2
     assert d["config"]["columns_per_gpu"] == 4194304 // 2 and d["config"]["columns_total"] == 4194304
     assert "configs[4]" in d["config"]["workload"] and "fp32" in d["metric"]
-    q = _run("--gpus", "1", "--config", "5", "--dry-run")
+    q = _run("--gpus", "1", "--config", "5", *DRY)
     assert q.returncode == 0, q.stderr[-3000:]
     d1 = json.loads(q.stdout.strip().splitlines()[-1])
     assert d1["config"]["columns_per_gpu"] == 4194304 and d1["n_gpus"] == 1 and d1["rccl_ranks"] is None
@@ -49,11 +74,12 @@ def test_config5_is_the_fixed_fp32_problem_split_over_the_gpus():
 
 def test_eight_ranks_config5_rehearsal():
     """The shape of the driver's 8-GPU scaling run of BASELINE configs[4], rehearsed on gloo: 8 ranks x 524 288 columns."""
-    p = _run("--gpus", "8", "--config", "5", "--dry-run")
+    p = _run("--gpus", "8", "--config", "5", *DRY)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.strip()]
     assert len(lines) == 1
     d = json.loads(lines[0])
+    _nrank_record_is_complete(d, 8, real_kernels=False)
     assert d["n_gpus"] == 8 and d["rccl_ranks"] == 8 and d["config"]["columns_per_gpu"] == 524288
     assert d["shard_check"]["col0_sum"] == 524288.0 * sum(range(8))          # ranks own columns [r * 524288, (r+1) * 524288)
 
@@ -61,9 +87,10 @@ def test_eight_ranks_config5_rehearsal():
 def test_eight_ranks_default_mode_rehearsal_carries_per_rank_times():
     """The default (weak, fp64) mode at the driver's N = 8, rehearsed on gloo without kernels: 8 x 65 536 columns, and the
     record carries every rank's own time (a straggler must be visible in the first real SCALE line)."""
-    p = _run("--gpus", "8", "--dry-run")
+    p = _run("--gpus", "8", *DRY)
     assert p.returncode == 0, p.stderr[-3000:]
     d = json.loads([l for l in p.stdout.splitlines() if l.strip()][0])
+    _nrank_record_is_complete(d, 8, real_kernels=False)
     assert d["n_gpus"] == 8 and d["rccl_ranks"] == 8 and d["scaling"] == "weak" and d["dtype"] == "f64"
     assert d["config"]["columns_per_gpu"] == 65536 and d["config"]["columns_total"] == 8 * 65536
     assert d["per_rank_ms"] == pytest.approx([1.0 * (r + 1) for r in range(8)]) and d["per_rank_ms_min_max"] == pytest.approx([1.0, 8.0])
@@ -147,9 +174,9 @@ def test_concurrent_builds_of_eight_ranks_run_make_once(tmp_path):
 
 
 def test_world_size_mismatch_and_bad_splits_are_refused():
-    p = _run("--gpus", "2", "--dry-run", env={"WORLD_SIZE": "3", "RANK": "0"})
+    p = _run("--gpus", "2", *DRY, env={"WORLD_SIZE": "3", "RANK": "0"})
     assert p.returncode != 0 and "WORLD_SIZE=3" in (p.stderr + p.stdout)
-    p = _run("--gpus", "3", "--config", "5", "--dry-run")
+    p = _run("--gpus", "3", "--config", "5", *DRY)
     assert p.returncode != 0 and "do not split" in p.stderr
 
 
@@ -203,15 +230,16 @@ def test_two_ranks_with_real_kernels_reproduce_the_one_process_result(gpu):
     """`--collective gloo`: the N-rank path with REAL kernels on fewer GPUs than ranks (both ranks on this box's one GPU; barrier
     and reductions through gloo).  Two shards of 8 192 columns must give the validation norms of ONE process on the same
     16 384 global columns - the shards are slices of one problem, eta comes from global column 0, the SUM all-reduce adds up."""
-    common = ("--steps", "3", "--warmup", "1", "--cpu-cols", "0", "--no-extra-rooflines", "--no-roofline-events",
-              "--placement", "separate")
-    one = _run("--cols", "16384", *common)
+    common = ("--steps", "3", "--warmup", "1", "--no-extra-rooflines", "--placement", "separate")
+    one = _run("--cols", "16384", "--cpu-cols", "0", "--no-roofline-events", *common)
     assert one.returncode == 0, one.stderr[-3000:]
-    two = _run("--gpus", "2", "--collective", "gloo", "--cols", "8192", *common)
+    two = _run("--gpus", "2", "--collective", "gloo", "--cols", "8192", "--cpu-cols", "256", "--cpu-budget-s", "0.5", *common)
     assert two.returncode == 0, two.stderr[-3000:]
     lines = [l for l in two.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, two.stdout[-2000:]
     d1, d2 = json.loads(one.stdout.strip().splitlines()[-1]), json.loads(lines[0])
+    _nrank_record_is_complete(d2, 2, real_kernels=True)      # cpu_baseline (+ parity check), roofline, per-rank outcomes at N = 2
+    assert "[bench] rank 1: import" in two.stderr            # every rank prints its start-up times
     assert d2["n_gpus"] == 2 and d2["rehearsal_ranks"] == 2 and d2["rccl_ranks"] is None
     assert d2["collective_backend"].startswith("gloo (rehearsal")
     assert d2["config"]["columns_per_gpu"] == 8192 and d2["config"]["columns_total"] == 16384 == d1["config"]["columns_total"]

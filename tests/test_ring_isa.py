@@ -89,3 +89,23 @@ def test_register_budgets_of_the_default_kernels(nl_asm, tl_asm, ad_asm):
     """No scratch in the kernels the drivers' defaults run; cloudsc2_ad fp32 keeps three waves per SIMD."""
     res = isa.check_resources(nl_asm, tl_asm, ad_asm)
     assert res["ad f32"]["Occupancy"] == 3 and res["ad f64"]["NumVgprs"] <= 256
+
+
+def test_inline_asm_memory_instructions_must_carry_their_base_pointer(nl_asm, tl_asm, ad_asm):
+    """VERDICT / ADVICE r03: no hand-written memory instruction goes to a GPU before its ISA text has been checked here.  The
+    shipped sources hold none (the loads / stores are compiler-generated, the LDS-DMAs come from a builtin); the guard
+    accepts the `v_off, s[base:base+1]` form and rejects what the lost round-3 variant must have looked like - a store whose
+    address is the 32-bit byte offset alone (the fault addresses 0x4000 / 0xa000 were exactly such offsets)."""
+    for asm, name in ((nl_asm, "nl"), (tl_asm, "tl"), (ad_asm, "ad")):
+        assert isa.check_inline_asm_vmem(asm, name) == 0
+    good = ";;#ASMSTART\n\tglobal_store_dwordx2 v37, v[4:5], s[84:85] sc1\n;;#ASMEND\n"
+    assert isa.check_inline_asm_vmem(good) == 1
+    compiler_generated = "\tglobal_store_dwordx2 v[100:101], v[102:103], off nt\n"      # outside an asm block: not judged
+    assert isa.check_inline_asm_vmem(compiler_generated) == 0
+    for bad in ("global_store_dwordx2 v[36:37], v[4:5], off sc1",          # 64-bit VGPR "address" = the zero-extended offset
+                "global_store_dwordx2 v37, v[4:5], off sc1",
+                "global_load_dwordx2 v[4:5], v[36:37], off",
+                "flat_store_dwordx2 v[36:37], v[4:5]",
+                "buffer_store_dwordx2 v[4:5], v37, s[8:11], 0 offen"):
+        with pytest.raises(AssertionError, match="does not use the `v_off, s\\[base:base\\+1\\]` form"):
+            isa.check_inline_asm_vmem(f";;#ASMSTART\n\t{bad}\n;;#ASMEND\n", "mutant")

@@ -80,10 +80,23 @@ def test_tuned_placement_is_bit_identical_and_reports_what_it_did(gpu):
     assert ("first_stage" in rep2) == st2["chosen"] and rep2["tuned_ms"] > 0
     for k, src in sources.items():
         assert torch.equal(storage.klayout(tuned2[k]), src), k
+    # the stage re-times both winners AFTER placing them - the returned fields must be back to the documented
+    # state all the same (inputs = sources, output-only fields zero), whichever stage won
+    for k in order:
+        if k not in sources:
+            assert float(tuned2[k].abs().sum()) == 0.0, k
     step(tuned2)
     torch.cuda.synchronize()
     for n in NL_OUT:
         assert torch.equal(tuned2["out_" + n], sep["out_" + n]), n
+    # the second stage runs only where the arena cap can reach its shifts - with a cap below the first
+    # extension shift it is SKIPPED (no `second_stage` in the report, one arena), and when it runs the report says so (above)
+    span = len(order) * rep2.get("slab_bytes", rep["slab_bytes"])
+    tuned3, rep3 = storage.tune_placement(nx, nz, np.float64, gpu, order, sources, step, spacings=(0, 1), staggers=(2304,),
+                                          budget_s=0.3, extend_shifts_mb=(64, 128), extend_below_gain=1.0,
+                                          extend_min_span_bytes=0, shifts_mb=(0,), max_arena_bytes=span + (48 << 20))
+    assert "second_stage" not in rep3 and "first_stage" not in rep3 and rep3["shift_MB"] == 0
+    assert rep3["arena_bytes"] <= span + (48 << 20)
 
 
 @pytest.mark.gpu

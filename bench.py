@@ -323,10 +323,12 @@ def rank0_then_everyone(dist, rank, work, key="bench/rank0_done", timeout_s=900)
 # ------------------------------------------------------------------------------------------------ PMC traffic
 _PMC_FILES = (
     # (columns, precision) -> summaries of the separate FETCH_SIZE / WRITE_SIZE passes, newest round first
-    ((65536, "double"), ("profiles/r03/nl_fp64_65536_pmc.json", "profiles/r03/all_kernels_fp64_65536_pmc.json",
+    ((65536, "double"), ("profiles/r04/nl_fp64_65536_pmc.json", "profiles/r04/all_kernels_fp64_65536_pmc.json",
+                         "profiles/r03/nl_fp64_65536_pmc.json", "profiles/r03/all_kernels_fp64_65536_pmc.json",
                          "profiles/r02/nl_fp64_65536_pmc.json", "profiles/r02/all_kernels_fp64_65536_pmc.json",
                          "profiles/r01/nl_fp64_65536_pmc.json", "profiles/r01/all_kernels_fp64_65536_pmc.json")),
-    ((524288, "single"), ("profiles/r03/all_kernels_fp32_524288_pmc.json", "profiles/r02/all_kernels_fp32_524288_pmc.json")),
+    ((524288, "single"), ("profiles/r04/all_kernels_fp32_524288_pmc.json", "profiles/r03/all_kernels_fp32_524288_pmc.json",
+                          "profiles/r02/all_kernels_fp32_524288_pmc.json")),
 )
 
 
@@ -903,7 +905,6 @@ def main(argv=None):
 
         def extra_rooflines():
             out = {}
-            Z = lambda: storage.zeros(nx, nz, np_dtype, device)  # noqa: E731
             extn = dict(ext, NLEV=nz)
             KL = storage.klayout
             tuned = args.placement == "tuned"
@@ -922,46 +923,55 @@ def main(argv=None):
                 for _ in range(max(3, int(ms / max(a.elapsed_time(b) / 3, 1e-3)))):
                     call()
 
-            def placed(order, sources, launch):
-                """fields of a leg: tuned placement (objective = the leg's own launch) or the default arenas"""
-                if tuned:
-                    Ft_, rep_ = storage.tune_placement(nx, nz, np_dtype, device, order, sources, launch)
-                    rep_["mode"] = "tuned"
-                    return faster_of_tuned_and_plain(Ft_, launch, rep_, np_dtype), rep_
-                Fd = {k: (storage.from_klayout(sources[k], np_dtype, device) if sources.get(k) is not None else Z())
-                      for k in order}
-                return Fd, {"mode": args.placement}
+            def tl_ad_legs(n_c, dt_np, ins_c, eta_c, sfx, reps):
+                """`roofline_tl<sfx>` / `roofline_ad<sfx>`: cloudsc2_tl on (state, 0.01 x state), then cloudsc2_ad forced with
+                the TL perturbation outputs, `n_c` columns of dtype `dt_np`, each on its own (tuned or default) placement"""
+                w = np.dtype(dt_np).itemsize
+                prec = "double" if w == 8 else "single"
+                Zc = lambda: storage.zeros(n_c, nz, dt_np, device)  # noqa: E731
 
-            inc_out = {"out_" + n + "_i": Z() for n in INC}
-            compile_stencil("state_increment", {"IGNORE_SUPSAT": True})(
-                **{"in_" + n: ins["in_" + n] for n in INC}, **inc_out, f=0.01, domain=(nx, 1, nz + 1), **com)
-            tl = compile_stencil("cloudsc2_tl", extn)
-            tl_order = (["in_" + n for n in NL_IN] + ["in_" + n + "_i" for n in NL_IN] + ["out_" + n for n in NL_OUT]
-                        + ["out_" + n + "_i" for n in NL_OUT])
-            tl_src = {"in_" + n: KL(ins["in_" + n]) for n in NL_IN}
-            tl_src.update({"in_" + n + "_i": KL(inc_out["out_" + n + "_i"]) for n in NL_IN})
-            tl_launch = lambda Ft: tl(**Ft, in_eta=eta, dt=dt, domain=(nx, 1, nz + 1), **com)  # noqa: E731
-            Ft, tl_rep = placed(tl_order, tl_src, tl_launch)
-            del inc_out, tl_src
-            tl_call = lambda: tl_launch(Ft)  # noqa: E731
-            steady(tl_call)
-            tl_name = last_kernel()
-            tl_ms = event_times(tl_call, 20)
-            out["roofline_tl"] = roofline_entry(tl_name, TLAD_WORDS_PER_COL, wsize, nx, args.precision, tl_ms, placement=tl_rep)
-            ad = compile_stencil("cloudsc2_ad", extn)
-            ad_order = (["in_" + n for n in NL_IN] + ["in_" + n + "_i" for n in NL_OUT] + ["out_" + n for n in NL_OUT]
-                        + ["out_" + n + "_i" for n in NL_IN])
-            ad_src = {"in_" + n: KL(ins["in_" + n]) for n in NL_IN}
-            ad_src.update({"in_" + n + "_i": KL(Ft["out_" + n + "_i"]) for n in NL_OUT})      # forced with the TL perturbations
-            ad_launch = lambda Fa: ad(**Fa, in_eta=eta, dt=dt, domain=(nx, 1, nz + 1), **com)  # noqa: E731
-            Fa, ad_rep = placed(ad_order, ad_src, ad_launch)
-            del Ft, ad_src
-            ad_call = lambda: ad_launch(Fa)  # noqa: E731
-            steady(ad_call)
-            ad_name = last_kernel()
-            ad_ms = event_times(ad_call, 20)
-            out["roofline_ad"] = roofline_entry(ad_name, TLAD_WORDS_PER_COL, wsize, nx, args.precision, ad_ms, placement=ad_rep)
-            del Fa
+                def placed(order_, sources_, launch_):
+                    if tuned:
+                        Ft_, rep_ = storage.tune_placement(n_c, nz, dt_np, device, order_, sources_, launch_)
+                        rep_["mode"] = "tuned"
+                        return faster_of_tuned_and_plain(Ft_, launch_, rep_, dt_np), rep_
+                    Fd = {k: (storage.from_klayout(sources_[k], dt_np, device) if sources_.get(k) is not None else Zc())
+                          for k in order_}
+                    return Fd, {"mode": args.placement}
+
+                inc_out = {"out_" + n + "_i": Zc() for n in INC}
+                compile_stencil("state_increment", {"IGNORE_SUPSAT": True})(
+                    **{"in_" + n: ins_c["in_" + n] for n in INC}, **inc_out, f=0.01, domain=(n_c, 1, nz + 1), **com)
+                tl = compile_stencil("cloudsc2_tl", extn)
+                tl_order = (["in_" + n for n in NL_IN] + ["in_" + n + "_i" for n in NL_IN] + ["out_" + n for n in NL_OUT]
+                            + ["out_" + n + "_i" for n in NL_OUT])
+                tl_src = {"in_" + n: KL(ins_c["in_" + n]) for n in NL_IN}
+                tl_src.update({"in_" + n + "_i": KL(inc_out["out_" + n + "_i"]) for n in NL_IN})
+                tl_launch = lambda Ft: tl(**Ft, in_eta=eta_c, dt=dt, domain=(n_c, 1, nz + 1), **com)  # noqa: E731
+                Ft, tl_rep = placed(tl_order, tl_src, tl_launch)
+                del inc_out, tl_src
+                tl_call = lambda: tl_launch(Ft)  # noqa: E731
+                steady(tl_call)
+                tl_name = last_kernel()
+                tl_ms = event_times(tl_call, reps)
+                out["roofline_tl" + sfx] = roofline_entry(tl_name, TLAD_WORDS_PER_COL, w, n_c, prec, tl_ms, placement=tl_rep)
+                ad = compile_stencil("cloudsc2_ad", extn)
+                ad_order = (["in_" + n for n in NL_IN] + ["in_" + n + "_i" for n in NL_OUT] + ["out_" + n for n in NL_OUT]
+                            + ["out_" + n + "_i" for n in NL_IN])
+                ad_src = {"in_" + n: KL(ins_c["in_" + n]) for n in NL_IN}
+                ad_src.update({"in_" + n + "_i": KL(Ft["out_" + n + "_i"]) for n in NL_OUT})      # forced with the TL perturbations
+                ad_launch = lambda Fa: ad(**Fa, in_eta=eta_c, dt=dt, domain=(n_c, 1, nz + 1), **com)  # noqa: E731
+                Fa, ad_rep = placed(ad_order, ad_src, ad_launch)
+                del Ft, ad_src
+                ad_call = lambda: ad_launch(Fa)  # noqa: E731
+                steady(ad_call)
+                ad_name = last_kernel()
+                ad_ms = event_times(ad_call, reps)
+                out["roofline_ad" + sfx] = roofline_entry(ad_name, TLAD_WORDS_PER_COL, w, n_c, prec, ad_ms, placement=ad_rep)
+                del Fa
+                torch.cuda.empty_cache()
+
+            tl_ad_legs(nx, np_dtype, ins, eta, "", 20)
             # cloudsc2_nl fp32 at the per-GPU shard of BASELINE configs[4] on 8 GPUs (524 288 columns)
             n32 = CONFIG5_COLUMNS // 8
             s32 = make_resident_state(n32, nz, 0, n32, np.float32, device)
@@ -991,7 +1001,14 @@ def main(argv=None):
             out["roofline_nl_f32"] = roofline_entry(name32, NL_WORDS_PER_COL, 4, n32, "single", ms32, placement=rep32,
                                                       what="per-GPU shard of BASELINE configs[4] on 8 GPUs, timed "
                                                            "inside the (saturation, cloudsc2_nl) pattern")
+            # cloudsc2_tl / cloudsc2_ad fp32 at the same shard (run_taylor_test.py / run_symmetry_test.py `--precision single`)
+            ins32 = {k: v for k, v in F32.items() if k.startswith("in_")}
             del F32
+            try:
+                tl_ad_legs(n32, np.float32, ins32, eta32, "_f32", 10)
+            except Exception as exc:  # noqa: BLE001 - e.g. a shared device without room: the fp64 legs stand
+                out["extra_rooflines_f32_error"] = f"{type(exc).__name__}: {exc}"[:300]
+            del ins32
             torch.cuda.empty_cache()
             return out
 

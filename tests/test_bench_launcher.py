@@ -206,11 +206,16 @@ def test_bench_line_carries_the_contract_on_the_gpu(gpu):
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["dtype"] == "f64" and d["vs_baseline"] is None
     assert d["unit"] == "columns/s" and d["value"] > 1e7 and d["outputs_finite"] is True
     assert "workload" in d["config"] and "model" not in d["config"]
-    for k in ("roofline", "roofline_tl", "roofline_ad", "roofline_nl_f32"):
+    assert "extra_rooflines_error" not in d and "extra_rooflines_f32_error" not in d, d.get("extra_rooflines_f32_error")
+    for k in ("roofline", "roofline_tl", "roofline_ad", "roofline_nl_f32", "roofline_tl_f32", "roofline_ad_f32"):
         r = d[k]
         assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and 0.2 < r["frac"] < 1.0, (k, r)
         assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["kernel"].startswith("cs2::")
     assert d["roofline"]["kernel"] == "cs2::nl_ring_kernel" and d["roofline_tl"]["kernel"] == "cs2::tl_kernel"
+    # run_taylor_test.py / run_symmetry_test.py `--precision single` at the per-GPU shard of BASELINE configs[4]
+    for k, kern in (("roofline_tl_f32", "cs2::tl_ring_kernel"), ("roofline_ad_f32", "cs2::ad_kernel")):
+        assert d[k]["kernel"] == kern and d[k]["dtype"] == "f32" and d[k]["columns"] == 524288, d[k]
+        assert d[k]["bytes_per_launch"] == 7134 * 4 * 524288
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
     pc = d["cpu_baseline"]["parity_check"]       # the HIP step on the baseline's own columns, held to the C restatement
     assert pc["passed"] and pc["points_outside_tolerance"] == 0 and pc["columns"] == 256 and pc["fields"] == 11
@@ -218,7 +223,8 @@ def test_bench_line_carries_the_contract_on_the_gpu(gpu):
     assert d["fused_step"]["results_equal_unfused"] is True
     # the tuner's winner was held against plain allocations before the timed region, in the headline and in every leg, and
     # the record says which one was timed; the untuned figure stands beside `value`
-    for rep in (d["placement"], d["roofline_tl"]["placement"], d["roofline_ad"]["placement"], d["roofline_nl_f32"]["placement"]):
+    for rep in (d["placement"], d["roofline_tl"]["placement"], d["roofline_ad"]["placement"], d["roofline_nl_f32"]["placement"],
+                d["roofline_tl_f32"]["placement"], d["roofline_ad_f32"]["placement"]):
         assert rep["chosen"].startswith(("tuned arena", "plain allocations")), rep
         assert rep["recheck_tuned_ms"] > 0 and rep["recheck_plain_ms"] > 0
         assert (rep["mode"] == "separate") == rep["chosen"].startswith("plain")

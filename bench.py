@@ -529,15 +529,19 @@ def harness_bench(args, rank, local_rank, world):
         return SymmetryTest(grid, factor=0.01, kflag=1, lphylin=True, ldrain1d=False, **common)
 
     sat_b, nl_b, tl_b = SAT_WORDS_PER_COL, NL_WORDS_PER_COL, TLAD_WORDS_PER_COL
-    pnl_words = 2 * 2193 + 1374                    # perturbed NL run fused: 32 fields read, 10 written (or 10 references read)
+    pnl_words = 2 * 2193 + 1374                    # perturbed NL run fused: 32 fields read, 10 references read (or 10 written)
     if taylor:
         seq_words = {"plain": sat_b + nl_b + INC_WORDS_PER_COL + tl_b + 10 * (PERT_WORDS_PER_COL + nl_b),     # 117 438
                      "fused": sat_b + nl_b + INC_WORDS_PER_COL + tl_b + 10 * pnl_words,
                      # fused_all: state_increment is fused into cloudsc2_tl (16 + 20 fields) and into the two multi-step launches
                      # (16 state + 10 reference fields read each)
                      "fused_all": sat_b + nl_b + (2193 + 2 * 1374) + 2 * (2193 + 1374)}
+        # fused: perturbation in the NL loads + the sums in the NL epilogue, one launch per step size (r04 default of --fused);
+        # fused_stored: the r03 meaning of "fused" (perturbed outputs stored, sums as separate launches)
         variants = [("graph", dict(graph=True), "plain"), ("fused", dict(fused=True), "fused"),
-                    ("fused_graph", dict(fused=True, graph=True), "fused"), ("fused_all", dict(fused_all=True), "fused_all"),
+                    ("fused_graph", dict(fused=True, graph=True), "fused"),
+                    ("fused_stored_graph", dict(fused=True, store_perturbed=True, graph=True), "fused"),
+                    ("fused_all", dict(fused_all=True), "fused_all"),
                     ("fused_all_graph", dict(fused_all=True, graph=True), "fused_all")]
         what = ("saturation + cloudsc2_nl + state_increment + cloudsc2_tl + 10 x (perturbed_state + cloudsc2_nl) + the "
                 "norms' reductions (tangent_linear/validation.py:150-181)")

@@ -16,7 +16,8 @@ def core(args):
                     lphylin=True, ldrain1d=False, yoethf_params=p["yoethf"], yomcst_params=p["yomcst"],
                     yrecldp_params=p["yrecldp"], yrephli_params=p["yrephli"], yrncl_params=p["yrncl"],
                     yrphnc_params=p["yrphnc"], enable_checks=cfg.sympl_enable_checks, gt4py_config=cfg.gt4py_config,
-                    fused=args.fused, fused_norms=args.fused_norms, fused_all=args.fused_all, graph=args.graph)
+                    fused=args.fused or args.fused_stored, fused_norms=args.fused_norms, fused_all=args.fused_all,
+                    graph=args.graph, store_perturbed=args.fused_stored)
     norms = tt.run(ctx["state"], ctx["dt"])                  # warm-up; these norms are the validated ones
     if args.output_csv_file_stencils is not None and not args.graph:
         cfg.gt4py_config.reset_exec_info()                    # run_taylor_test.py:93: per-stencil HIP events from here on
@@ -71,9 +72,12 @@ def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__)
     add_common_options(ap)
     ap.add_argument("--fused", action="store_true",
-                    help="apply the perturbation inside the NL kernel (build extension cloudsc2_nl_perturbed)")
-    ap.add_argument("--fused-norms", action="store_true",
-                    help="--fused + the ten difference sums formed in the kernel epilogue (cloudsc2_nl_taylor)")
+                    help="apply the perturbation inside the NL kernel's loads and form the ten difference sums in its epilogue: "
+                         "one launch per step size, nothing stored (build extension cloudsc2_nl_taylor)")
+    ap.add_argument("--fused-norms", action="store_true", help="older name of --fused")
+    ap.add_argument("--fused-stored", action="store_true",
+                    help="perturbation inside the NL kernel's loads, perturbed outputs stored, sums as separate launches "
+                         "(build extension cloudsc2_nl_perturbed; norms bit-equal to the unfused sequence)")
     ap.add_argument("--fused-all", action="store_true",
                     help="all ten perturbed runs in two launches that share the loads of a level and form the sums in "
                          "their epilogue (build extension cloudsc2_nl_taylor_multi)")

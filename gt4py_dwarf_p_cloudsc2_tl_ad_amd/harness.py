@@ -9,9 +9,12 @@ observable contract).  Differences, all on the measurement side:
     maximum all-reduced (MAX) over the column shards - the only communication of the whole path;
   * every reduction is ONE kernel launch per group of fields (`reductions.field_sums` / `column_dots`) and the host
     reads the sums back ONCE per run (one all-reduce of (1 + number of step sizes) x 10 doubles across ranks);
-  * `TaylorTest(..., fused=True)` applies the perturbation inside the NL kernel's loads (stencil `cloudsc2_nl_perturbed`);
-    `fused_norms=True` additionally forms the ten sums of NL(x + f x_i) - NL(x) in that kernel's epilogue (stencil
-    `cloudsc2_nl_taylor`: no perturbed outputs are stored, no separate difference / sum kernels run);
+  * `TaylorTest(..., fused=True)` applies the perturbation inside the NL kernel's loads AND forms the ten sums of
+    NL(x + f x_i) - NL(x) in that kernel's epilogue (stencil `cloudsc2_nl_taylor`: no perturbed outputs are stored, no
+    separate difference / sum launches - they were 23 % of the run's kernel time, r03); `fused_norms=True` is the same
+    thing under its older name; `fused=True, store_perturbed=True` keeps the r02/r03 behaviour (stencil
+    `cloudsc2_nl_perturbed`: the perturbed outputs of the last step size stay available in `tends_nl_p` / `diags_nl_p`, as
+    in the reference, and the sums are a separate launch per step size);
     `fused_all=True` evaluates ALL step sizes in ceil(n / 5) launches that share the loads of a level (stencil
     `cloudsc2_nl_taylor_multi`): the ten perturbed runs become bound by arithmetic instead of re-streaming the state -
     and `state_increment` is fused into cloudsc2_tl and into that kernel (stencil `cloudsc2_tl_incremented`, `f_inc=`):
@@ -104,10 +107,11 @@ class TaylorTest:
     def __init__(self, computational_grid, factor1: float, factor2s: Tuple[float, ...], kflag: int, lphylin: bool,
                  ldrain1d: bool, yoethf_params, yomcst_params, yrecldp_params, yrephli_params, yrncl_params,
                  yrphnc_params, *, enable_checks: bool = True, gt4py_config, fused: bool = False,
-                 fused_norms: bool = False, fused_all: bool = False, graph: bool = False) -> None:
+                 fused_norms: bool = False, fused_all: bool = False, graph: bool = False,
+                 store_perturbed: bool = False) -> None:
         self.f1, self.f2s = factor1, tuple(factor2s)
         self.fused_all = fused_all
-        self.fused_norms = fused_norms or fused_all
+        self.fused_norms = fused_norms or fused_all or (fused and not store_perturbed)
         self.fused = fused or self.fused_norms
         self.graph = graph
         self._graphed: Optional[_GraphedRun] = None

@@ -277,7 +277,7 @@ def test_bench_lines_of_configs_3_and_4(gpu, config):
     if config == 3:
         assert d["verdict"]["verdict"].startswith("The test passed with penalty") and len(d["verdict"]["norms"]) == 10
         assert r["stencils_one_step"]["cloudsc2_nl"]["ncalls"] == 11 and r["stencils_one_step"]["perturbed_state"]["ncalls"] == 10
-        for name in ("graph", "fused", "fused_graph", "fused_all", "fused_all_graph"):
+        for name in ("graph", "fused", "fused_graph", "fused_stored_graph", "fused_all", "fused_all_graph"):
             v = d["variants"][name]
             assert "error" not in v and v["verdict"] == d["verdict"]["verdict"], (name, v)
     else:

@@ -313,24 +313,28 @@ def test_fused_driver_variants_match_the_unfused_ones(gpu, capsys):
         for k, v in a[d].items():
             assert torch.equal(v.data, b[d][k].data), k
     t0 = run_taylor_test.main(["--backend", "hip", "--num-cols", "4096", "--disable-validation"])
-    t1 = run_taylor_test.main(["--backend", "hip", "--num-cols", "4096", "--disable-validation", "--fused"])
+    t1 = run_taylor_test.main(["--backend", "hip", "--num-cols", "4096", "--disable-validation", "--fused-stored"])
     np.testing.assert_allclose(t1["norms"], t0["norms"], rtol=1e-12)
+    assert t1["harness"].fused and not t1["harness"].fused_norms and t1["harness"].tends_nl_p      # perturbed outputs kept
     capsys.readouterr()
 
 
 @pytest.mark.gpu
 def test_taylor_driver_with_fused_norms(gpu, capsys):
-    """`--fused-norms`: the whole perturbation step (perturb, NL, difference, sums) is one kernel launch; the verdict
-    and the norms are those of the unfused harness (summation order differs, so compare the error |1 - norm| loosely)."""
+    """`--fused` (= `--fused-norms`, its older name): the whole perturbation step (perturb, NL, difference, sums) is one kernel
+    launch; the verdict and the norms are those of the unfused harness (summation order differs, so compare the error
+    |1 - norm| loosely)."""
     from gt4py_dwarf_p_cloudsc2_tl_ad_amd.drivers import run_taylor_test
-
-    t0 = run_taylor_test.main(["--backend", "hip", "--num-cols", "4096", "--disable-validation"])
-    t1 = run_taylor_test.main(["--backend", "hip", "--num-cols", "4096", "--disable-validation", "--fused-norms"])
     from gt4py_dwarf_p_cloudsc2_tl_ad_amd.harness import taylor_verdict
 
-    assert taylor_verdict(t0["norms"])[0] and taylor_verdict(t1["norms"])[0]
-    np.testing.assert_allclose(t1["norms"][:6], t0["norms"][:6], rtol=1e-7)
-    np.testing.assert_allclose(t1["norms"], t0["norms"], rtol=1e-2)
+    t0 = run_taylor_test.main(["--backend", "hip", "--num-cols", "4096", "--disable-validation"])
+    for flag in ("--fused", "--fused-norms"):
+        t1 = run_taylor_test.main(["--backend", "hip", "--num-cols", "4096", "--disable-validation", flag])
+        assert t1["harness"].fused_norms and not t1["harness"].tends_nl_p           # nothing stored per step size
+        assert taylor_verdict(t0["norms"])[0] and taylor_verdict(t1["norms"])[0]
+        assert taylor_verdict(t0["norms"])[1] == taylor_verdict(t1["norms"])[1]     # the reference's verdict string, unchanged
+        np.testing.assert_allclose(t1["norms"][:6], t0["norms"][:6], rtol=1e-7)
+        np.testing.assert_allclose(t1["norms"], t0["norms"], rtol=1e-2)
     capsys.readouterr()
 
 

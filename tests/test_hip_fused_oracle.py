@@ -246,13 +246,13 @@ def _taylor_ctx(argv):
 
 @pytest.mark.parametrize("precision", ["double", "single"])
 def test_taylor_driver_modes_agree(gpu, precision, capsys):
-    """plain, --fused, --fused-norms, --fused-all, --graph (alone and with the fused modes): the same norms (summation
+    """plain, --fused (= --fused-norms), --fused-stored, --fused-all, --graph (alone and with the fused modes): the same norms (summation
     order apart) and the same verdict of the reference's scoring rule, on the reader path and on distinct columns"""
     for inp, cols in (("auto", 4096), ("synthetic", 3000)):
         base = _taylor_ctx(["--num-cols", str(cols), "--input", inp, "--precision", precision])
         verdict = [l for l in capsys.readouterr().out.splitlines() if l.startswith("The test ")]
-        for extra in (["--fused"], ["--fused-norms"], ["--fused-all"], ["--graph"], ["--fused", "--graph"],
-                      ["--fused-all", "--graph"]):
+        for extra in (["--fused"], ["--fused-norms"], ["--fused-stored"], ["--fused-all"], ["--graph"], ["--fused", "--graph"],
+                      ["--fused-stored", "--graph"], ["--fused-all", "--graph"]):
             ctx = _taylor_ctx(["--num-cols", str(cols), "--input", inp, "--precision", precision] + extra)
             out = [l for l in capsys.readouterr().out.splitlines() if l.startswith("The test ")]
             # norms: ratios of sums; a different summation order moves them by rounding only while the perturbation is

@@ -78,8 +78,8 @@ struct ADIn {
 
 // `keep`: wave-uniform; the level's 16 words are loaded with the default cache policy instead of non-temporally
 // (CS2_AD_KEEP_MB below: the levels where sweep 1 ends are the levels where sweep 2 starts).
-template <typename T, typename FP>
-__device__ __forceinline__ ADIn<T> ad_load(const FP& F, uint32_t lsb, uint32_t o, bool keep = false) {
+template <typename T, typename FP, typename O>
+__device__ __forceinline__ ADIn<T> ad_load(const FP& F, O lsb, O o, bool keep = false) {
     ADIn<T> x;
     if (keep) {
         x.ap = ldg_keep(F.in(NL_IN_AP), o);
@@ -119,13 +119,13 @@ __device__ __forceinline__ ADIn<T> ad_load(const FP& F, uint32_t lsb, uint32_t o
     return x;
 }
 // store / load with the cache policy chosen by a wave-uniform flag (sweep 1's fluxes that sweep 2 reads back)
-template <typename T>
-__device__ __forceinline__ void stg_sel(T* base, uint32_t boff, T v, bool keep) {
+template <typename T, typename O>
+__device__ __forceinline__ void stg_sel(T* base, O boff, T v, bool keep) {
     if (keep) *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + boff) = v;
     else stg(base, boff, v);
 }
-template <typename T>
-__device__ __forceinline__ T ldg_sel(const T* base, uint32_t boff, bool keep) {
+template <typename T, typename O>
+__device__ __forceinline__ T ldg_sel(const T* base, O boff, bool keep) {
     return keep ? ldg_keep(base, boff) : ldg(base, boff);
 }
 
@@ -512,8 +512,8 @@ struct ADForce {
     T covptot;                                            // read by the evaporation block only
 };
 
-template <typename T, bool EVAP, typename FP>
-__device__ __forceinline__ ADForce<T> ad_load_force(const FP& F, const Ext<T>& e, uint32_t lsb, uint32_t o) {
+template <typename T, bool EVAP, typename FP, typename O>
+__device__ __forceinline__ ADForce<T> ad_load_force(const FP& F, const Ext<T>& e, O lsb, O o) {
     ADForce<T> f;
     f.clc = ldg(F.adj(NL_OUT_CLC), o);
     f.tnd_q = ldg(F.adj(NL_OUT_TND_Q), o);
@@ -966,7 +966,8 @@ struct ADFields : KernArgs<ADArgs<T>> {
 
 // fp32 without the evaporation block: three waves per SIMD (<= 168 VGPRs) is what the LDS parking was built for (+4.7 %,
 // DESIGN 3.5); r03's two extra raw forcing words took the unconstrained allocation to 170 VGPRs = two waves, so it is asked for.
-template <typename T, bool REG, bool FIX, bool EVAP>
+// BIG: 64-bit byte offsets (fields of 4 GiB and more, see offset_t in cloudsc2_common.hpp).
+template <typename T, bool REG, bool FIX, bool EVAP, bool BIG = false>
 __global__ void __launch_bounds__(kColBlock, (sizeof(T) == 4 && !EVAP) ? 3 : 1)
 ad_kernel(const ADArgs<T> A) {
     Ext<T> e = A.e;
@@ -1000,14 +1001,15 @@ ad_kernel(const ADArgs<T> A) {
     T* const park_lds = s_scalm + (nz + 1) + threadIdx.x;
     (void)park_lds;
     if (gcol >= nx) return;  // no later workgroup barrier: whole lanes may retire
+    using O = offset_t<BIG>;
 #if CS2_AD_DIAG == 2
-    const uint32_t lsb = nz < 0 ? uint32_t(ls) : 0u;   // diagnostics only (wrong results): every level reads and writes level 0 -
+    const O lsb = nz < 0 ? O(ls) : O(0);   // diagnostics only (wrong results): every level reads and writes level 0 -
 #else                                                  // cache-resident rows, the kernel's time without HBM
-    const uint32_t lsb = uint32_t(ls) * uint32_t(sizeof(T));
+    const O lsb = O(ls) * O(sizeof(T));
 #endif
-    const uint32_t colb = uint32_t(gcol) * uint32_t(sizeof(T));
+    const O colb = O(gcol) * O(sizeof(T));
 
-    const T trpaus = trpaus_prescan<T>(F.in(NL_IN_T), F.in(NL_IN_TND_CML_T), lsb, colb, dt, s_eta, klo, khi);
+    const T trpaus = trpaus_prescan<T, false, O>(F.in(NL_IN_T), F.in(NL_IN_TND_CML_T), lsb, colb, dt, s_eta, klo, khi);
     const CrhCol<T> crh = crh_setup<T>(trpaus);
 
     // ---------------- sweep 1: trajectory + NL outputs (:146-475)
@@ -1015,12 +1017,12 @@ ad_kernel(const ADArgs<T> A) {
     stg(F.out(NL_OUT_FPLSN), colb, T(0.0));
     stg(F.out(NL_OUT_FHPSL), colb, T(0.0));
     stg(F.out(NL_OUT_FHPSN), colb, T(0.0));
-    const T aph_s = EVAP ? ldg(F.in(NL_IN_APH), uint32_t(nz) * lsb + colb) : T(1.0);
+    const T aph_s = EVAP ? ldg(F.in(NL_IN_APH), O(nz) * lsb + colb) : T(1.0);
     #define park F.oadj(NL_IN_MFD)  // EVAP: level k holds the cover entering level k until sweep 2 overwrites it
     {
         T rfl = T(0.0), sfl = T(0.0), covptot = T(0.0);
         T aph_k = ldg(F.in(NL_IN_APH), colb);
-        uint32_t o = colb;
+        O o = colb;
         ADIn<T> xa = ad_load<T>(F, lsb, o, 0 >= keep_from);
         if constexpr (CS2_AD_LANDED != 0) landed(aph_k);
         for (int k = 0; k < nz; ++k) {
@@ -1059,7 +1061,7 @@ ad_kernel(const ADArgs<T> A) {
     b.aph_s = aph_s;
     {
         int k = nz - 1;
-        uint32_t o = uint32_t(k) * lsb + colb;
+        O o = O(k) * lsb + colb;
         ADIn<T> xa = ad_load<T>(F, lsb, o, k >= keep_from);
         ADForce<T> fa = ad_load_force<T, EVAP>(F, e, lsb, o);
         T aph_k = ldg_sel(F.in(NL_IN_APH), o, k >= keep_from);
@@ -1072,7 +1074,7 @@ ad_kernel(const ADArgs<T> A) {
             ADForce<T> fn = fa;
             T aph_n = aph_k, sfl_n = sfl, rfl_n = rfl, cov_n = cov;
             if (k > 0) {
-                const uint32_t om = o - lsb;
+                const O om = o - lsb;
                 const bool keep_m = k - 1 >= keep_from;
                 xn = ad_load<T>(F, lsb, om, keep_m);
                 xn.aph1 = aph_k;   // aph[k]: already here as this level's upper half level (the load above is dropped)
@@ -1113,7 +1115,7 @@ ad_kernel(const ADArgs<T> A) {
         }
     }
     if constexpr (EVAP) {  // :970-971: out_aph_i[nz] also receives the accumulated tmp_aph_s_i
-        const uint32_t on = uint32_t(nz) * lsb + colb;
+        const O on = O(nz) * lsb + colb;
         stg(F.oadj(NL_IN_APH), on, ldg(F.oadjc(NL_IN_APH), on) + b.aph_s_i);
     }
     // :982-986 top half level
@@ -1138,7 +1140,7 @@ int launch_ad(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
     const T tdt = static_cast<T>(dt);
     const NLK<T> kc = make_nlk<T>(p, dt, evap);
     const ExpK<T> xk = make_expk<T>();
-    if (!fits_u32_offsets<T>(nz, ls)) return -2;
+    const bool big = !fits_u32_offsets<T>(nz, ls);
     if (smem > size_t(160) * 1024) return -2;
     int dev = 0;
     if (smem > size_t(64) * 1024)
@@ -1155,7 +1157,11 @@ int launch_ad(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
     const ADArgs<T> args = {e, kc, xk, nx, nz, ls, ci, ca, eta, co, coa, tdt, keep_from};
 #define CS2_AD_LAUNCH(R, F, E)                                                                                         \
     do {                                                                                                               \
-        auto kern = ad_kernel<T, R, F, E>;                                                                             \
+        if (big) CS2_AD_LAUNCH_B(R, F, E, true); else CS2_AD_LAUNCH_B(R, F, E, false);                                 \
+    } while (0)
+#define CS2_AD_LAUNCH_B(R, F, E, B)                                                                                    \
+    do {                                                                                                               \
+        auto kern = ad_kernel<T, R, F, E, B>;                                                                             \
         if (smem > size_t(64) * 1024) { /* > 64 KB of dynamic LDS needs the opt-in: once per instantiation and device */ \
             static std::atomic<size_t> attr_set[kMaxDevices] = {};                                                     \
             if (!lds_opt_in(kern, attr_set, dev, smem)) return -1;                                                     \
@@ -1172,7 +1178,8 @@ int launch_ad(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
     else CS2_AD_LAUNCH_E(false, true);
 #undef CS2_AD_LAUNCH_E
 #undef CS2_AD_LAUNCH
-    note_kernel("cs2::ad_kernel");
+#undef CS2_AD_LAUNCH_B
+    note_kernel(big ? "cs2::ad_kernel<big>" : "cs2::ad_kernel");
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

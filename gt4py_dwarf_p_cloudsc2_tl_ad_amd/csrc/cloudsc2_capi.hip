@@ -66,10 +66,11 @@ int check_ptrs(const char* fn, const char* what, const T* const* arr, int n) {
 
 int launched(const char* fn, int rc) {
     if (rc == 0) return CLOUDSC2_OK;
-    if (rc == -2)   // the launchers' refusals: a field of 4 GiB or more (32-bit byte offsets), or a device ordinal >= 64
+    if (rc == -2)   // the launchers' refusals: a fused build extension on fields of 4 GiB or more, or a device ordinal >= 64
         return fail(CLOUDSC2_E_UNSUPPORTED,
-                    "%s: (nz+1) * lev_stride * sizeof(element) must be < 2^32 bytes per field - split the columns into blocks "
-                    "(or: HIP device ordinal >= 64, LDS demand beyond one CU)", fn);
+                    "%s: this build extension keeps 32-bit byte offsets: (nz+1) * lev_stride * sizeof(element) must be < 2^32 "
+                    "bytes per field (the plain stencils cloudsc2_nl / _tl / _ad have no such limit: use them, or narrower "
+                    "allocations) (or: HIP device ordinal >= 64, LDS demand beyond one CU)", fn);
     return fail(CLOUDSC2_E_LAUNCH, "%s: HIP launch failed: %s", fn, hipGetErrorString(hipPeekAtLastError()));
 }
 

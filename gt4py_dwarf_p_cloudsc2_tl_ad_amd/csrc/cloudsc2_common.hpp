@@ -13,6 +13,7 @@
 #include <stdint.h>
 
 #include <atomic>
+#include <type_traits>
 
 #include "../../include/cloudsc2_hip.h"
 
@@ -240,8 +241,10 @@ __device__ __forceinline__ void drain_vmem() {
 #ifndef CS2_NT
 #define CS2_NT 3
 #endif
-template <typename T>
-__device__ __forceinline__ T ldg(const T* base, uint32_t boff) {
+// The offset type `O` is uint32_t in every kernel but the BIG instantiations (fields of 4 GiB and more, see kBigOffsets):
+// there it is uint64_t and hipcc emits the `v[a:a+1], off` form after a 64-bit VALU add per access.
+template <typename T, typename O>
+__device__ __forceinline__ T ldg(const T* base, O boff) {
     const T* a = reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + boff);
 #if CS2_NT & 1
     return __builtin_nontemporal_load(a);
@@ -249,8 +252,8 @@ __device__ __forceinline__ T ldg(const T* base, uint32_t boff) {
     return *a;
 #endif
 }
-template <typename T>
-__device__ __forceinline__ void stg(T* base, uint32_t boff, T v) {
+template <typename T, typename O>
+__device__ __forceinline__ void stg(T* base, O boff, T v) {
     T* a = reinterpret_cast<T*>(reinterpret_cast<char*>(base) + boff);
 #if CS2_NT & 2
     __builtin_nontemporal_store(v, a);
@@ -261,8 +264,8 @@ __device__ __forceinline__ void stg(T* base, uint32_t boff, T v) {
 // Default-policy load for the ONE field with a producer just upstream: `in_qsat` is written by `saturation` right before
 // cloudsc2_nl reads it (run_nonlinear.py:117-118) and, at 72 MB for 65 536 columns, is still in the 256 MB
 // memory-side cache - unless the store or the load is marked non-temporal (measured: saturation + NL 391 -> 370 us).
-template <typename T>
-__device__ __forceinline__ T ldg_keep(const T* base, uint32_t boff) {
+template <typename T, typename O>
+__device__ __forceinline__ T ldg_keep(const T* base, O boff) {
     return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + boff);
 }
 // streaming access for the pointwise helper kernels (64-bit indexing, same CS2_NT policy)
@@ -294,6 +297,13 @@ template <typename T>
 inline bool fits_u32_offsets(int nz, int64_t ls) {
     return static_cast<uint64_t>(nz + 1) * static_cast<uint64_t>(ls) * sizeof(T) <= 0xFFFFFFFFull;
 }
+// Fields of 4 GiB and more ((nz+1) * lev_stride * sizeof(T) > 2^32 - 1: 3.89 M fp64 columns at 137 levels): the plain
+// stencils (cloudsc2_nl / _tl / _ad) switch to the BIG instantiation of their register-path kernel, whose byte offsets are
+// 64-bit; the fused build extensions and the LDS-ring kernels keep 32-bit offsets and refuse such a call
+// (CLOUDSC2_E_UNSUPPORTED).  Columns are independent, so a caller can also split such a call into column windows of a
+// narrower allocation - but NOT into windows of the same allocation: the level stride, not nx, is what overflows.
+template <bool BIG>
+using offset_t = typename std::conditional<BIG, uint64_t, uint32_t>::type;
 
 // ---- field pointer bundles (kernel arguments, by value) --------------------------------------
 template <typename T, int N>
@@ -416,15 +426,15 @@ inline NLK<T> make_nlk(const Cloudsc2Params& p, double dt, bool evap) {
 // kernel, measured).  The loads of CH levels are therefore issued back to back and compared afterwards: 3 round
 // trips instead of 42.  (klo, khi) come from build_level_table; khi <= nz - 2, so level khi + 1 exists.
 // PERT: the state is read as x + pf * x_i (the fused perturbed_state variants), exactly as nl_perturb forms it.
-template <typename T, bool PERT = false>
-__device__ __forceinline__ T trpaus_prescan(const T* __restrict__ pt, const T* __restrict__ ptt, uint32_t lsb,
-                                            uint32_t colb, T dt, const T* s_eta, int klo, int khi,
+template <typename T, bool PERT = false, typename O = uint32_t>
+__device__ __forceinline__ T trpaus_prescan(const T* __restrict__ pt, const T* __restrict__ ptt, O lsb,
+                                            O colb, T dt, const T* s_eta, int klo, int khi,
                                             const T* __restrict__ pt_i = nullptr, const T* __restrict__ ptt_i = nullptr,
                                             T pf = T(0.0)) {
     T trpaus = T(0.1);
     if (klo > khi) return trpaus;
     constexpr int CH = PERT ? 8 : 16;
-    const uint32_t o0 = uint32_t(klo) * lsb + colb;
+    const O o0 = O(klo) * lsb + colb;
     T t0 = ldg(pt, o0), tt0 = ldg(ptt, o0);
     if constexpr (PERT) {
         t0 = t0 + pf * ldg(pt_i, o0);
@@ -436,7 +446,7 @@ __device__ __forceinline__ T trpaus_prescan(const T* __restrict__ pt, const T* _
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
             const int kk = (k0 + j < khi ? k0 + j : khi) + 1;   // the tail re-reads level khi + 1 (cache hits)
-            const uint32_t oj = uint32_t(kk) * lsb + colb;
+            const O oj = O(kk) * lsb + colb;
             a[j] = ldg(pt, oj);
             b[j] = ldg(ptt, oj);
             if constexpr (PERT) {

@@ -53,10 +53,10 @@ struct NLIn {
     T ap, aph1, lu1, lude, mfd, mfu, q, qi, ql, qsat, supsat, t, tq, tqi, tql, tt;
 };
 
-template <typename T>
-// `o` = byte offset of (level k, this lane's column); `lsb` = level stride in bytes.
-// SKIPQ: in_qsat is not read (the fused-saturation variant computes it).
-__device__ __forceinline__ NLIn<T> nl_load_impl(const CPtrs<T, NL_NUM_IN>& in, uint32_t lsb, uint32_t o, bool skipq,
+// `o` = byte offset of (level k, this lane's column); `lsb` = level stride in bytes (`O`: uint32_t, or uint64_t in the BIG
+// instantiation).  SKIPQ: in_qsat is not read (the fused-saturation variant computes it).
+template <typename T, typename O>
+__device__ __forceinline__ NLIn<T> nl_load_impl(const CPtrs<T, NL_NUM_IN>& in, O lsb, O o, bool skipq,
                                                  bool keepq = false) {
     NLIn<T> x;
     x.ap = ldg(in.p[NL_IN_AP], o);
@@ -79,9 +79,9 @@ __device__ __forceinline__ NLIn<T> nl_load_impl(const CPtrs<T, NL_NUM_IN>& in, u
     return x;
 }
 
-template <typename T, bool SKIPQ>
-__device__ __forceinline__ NLIn<T> nl_load(const CPtrs<T, NL_NUM_IN>& in, uint32_t lsb, uint32_t o, bool keepq = false) {
-    return nl_load_impl<T>(in, lsb, o, SKIPQ, keepq);
+template <typename T, bool SKIPQ, typename O>
+__device__ __forceinline__ NLIn<T> nl_load(const CPtrs<T, NL_NUM_IN>& in, O lsb, O o, bool keepq = false) {
+    return nl_load_impl<T, O>(in, lsb, o, SKIPQ, keepq);
 }
 
 // perturbed_state (common/_stencils/perturbed_state.py:75-91) applied on the fly: x + f * x_i.
@@ -339,8 +339,8 @@ __device__ __forceinline__ NLOut<T> nl_level(const Ext<T>& e, const NLK<T>& kc, 
     return o;
 }
 
-template <typename T>
-__device__ __forceinline__ void nl_store(const MPtrs<T, NL_NUM_OUT>& out, const Ext<T>& e, uint32_t lsb, uint32_t i,
+template <typename T, typename O>
+__device__ __forceinline__ void nl_store(const MPtrs<T, NL_NUM_OUT>& out, const Ext<T>& e, O lsb, O i,
                                          const NLOut<T>& o) {
     stg(out.p[NL_OUT_CLC], i, o.clc);
     stg(out.p[NL_OUT_COVPTOT], i, o.covptot);
@@ -379,7 +379,8 @@ __device__ __forceinline__ T enthalpy_diff(T flux, T latent, T ref) {
 //      outputs (read-only) and every workgroup writes the 10 sums  sum_{k, col in block}(NL(x + pf x_i) - NL(x))
 //      (tangent_linear/validation.py:239-249) to partials[block][field] in double precision.  One partial per
 //      workgroup, summed by the caller: deterministic, no atomics.
-template <typename T, bool EVAP, bool LIN, bool PINK, int FUSE>
+// BIG: 64-bit byte offsets (fields of 4 GiB and more, see offset_t); instantiated for FUSE = 0 only.
+template <typename T, bool EVAP, bool LIN, bool PINK, int FUSE, bool BIG = false>
 __global__ void __launch_bounds__(kColBlock, (sizeof(T) == 4 ? CS2_F32_WAVES : 1))
 nl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, NL_NUM_IN> in, const T* __restrict__ eta,
           MPtrs<T, NL_NUM_OUT> out, T dt, CPtrs<T, NL_NUM_IN> in_i, T pf, T* __restrict__ qsat_out,
@@ -418,19 +419,20 @@ nl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
 #endif
     const double wlive = gcol < nx ? 1.0 : 0.0;
     const int col = (gcol < nx) ? gcol : nx - 1;
+    using O = offset_t<BIG>;
 #if CS2_NL_DIAG == 2
-    const uint32_t lsb = 0;                  // every level reads level 0 (cache-resident)
+    const O lsb = 0;                         // every level reads level 0 (cache-resident)
 #else
-    const uint32_t lsb = uint32_t(ls) * uint32_t(sizeof(T));
+    const O lsb = O(ls) * O(sizeof(T));
 #endif
-    const uint32_t colb = uint32_t(col) * uint32_t(sizeof(T));
+    const O colb = O(col) * O(sizeof(T));
 
     // everything the fused-perturbed variants read outside nl_load is perturbed here as well: the pre-scan's t and
     // tnd_cml_t, aph at the top half level and at the surface
     constexpr bool PERTURBED = FUSE == 2 || FUSE == 3;
-    const T trpaus = PERTURBED ? trpaus_prescan<T, true>(in.p[NL_IN_T], in.p[NL_IN_TND_CML_T], lsb, colb, dt, s_eta, klo,
+    const T trpaus = PERTURBED ? trpaus_prescan<T, true, O>(in.p[NL_IN_T], in.p[NL_IN_TND_CML_T], lsb, colb, dt, s_eta, klo,
                                                          khi, in_i.p[NL_IN_T], in_i.p[NL_IN_TND_CML_T], pf)
-                               : trpaus_prescan<T>(in.p[NL_IN_T], in.p[NL_IN_TND_CML_T], lsb, colb, dt, s_eta, klo, khi);
+                               : trpaus_prescan<T, false, O>(in.p[NL_IN_T], in.p[NL_IN_TND_CML_T], lsb, colb, dt, s_eta, klo, khi);
     const CrhCol<T> crh = crh_setup<T>(trpaus);
 
     // :93-100
@@ -439,10 +441,10 @@ nl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
     c.sfl = T(0.0);
     c.covptot = T(0.0);
     c.aph_k = ldg(in.p[NL_IN_APH], colb);
-    T aph_s = EVAP ? ldg(in.p[NL_IN_APH], uint32_t(nz) * lsb + colb) : T(1.0);
+    T aph_s = EVAP ? ldg(in.p[NL_IN_APH], O(nz) * lsb + colb) : T(1.0);
     if constexpr (PERTURBED) {
         c.aph_k = c.aph_k + pf * ldg(in_i.p[NL_IN_APH], colb);
-        if constexpr (EVAP) aph_s = aph_s + pf * ldg(in_i.p[NL_IN_APH], uint32_t(nz) * lsb + colb);
+        if constexpr (EVAP) aph_s = aph_s + pf * ldg(in_i.p[NL_IN_APH], O(nz) * lsb + colb);
     }
 
     if (live && FUSE != 3) {
@@ -461,18 +463,18 @@ nl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
     // loads of every second level (the compiled ISA shows it: 16 / 32 loads, then the wait 0 / 19 instructions later), i.e.
     // every other level paid the full HBM latency.  Deeper register prefetch was measured in r01 (spills; 1 is best).
     constexpr bool PERT = FUSE == 2 || FUSE == 3;
-    NLIn<T> xa = nl_load<T, FUSE == 1>(in, lsb, colb, keepq != 0);
+    NLIn<T> xa = nl_load<T, FUSE == 1, O>(in, lsb, colb, keepq != 0);
     NLIn<T> xia;
-    if constexpr (PERT) xia = nl_load<T, false>(in_i, lsb, colb);
+    if constexpr (PERT) xia = nl_load<T, false, O>(in_i, lsb, colb);
     landed(c.aph_k);   // first read inside the loop: see landed()
     if constexpr (EVAP) landed(aph_s);
     double acc[FUSE == 3 ? NL_NUM_OUT : 1] = {};
-    uint32_t o = colb;  // byte offset of (level k, column)
+    O o = colb;  // byte offset of (level k, column)
     for (int k = 0; k < nz; ++k) {
         NLIn<T> xn = xa, xin = xia;
         if (k + 1 < nz) {
-            xn = nl_load<T, FUSE == 1>(in, lsb, o + lsb, keepq != 0);
-            if constexpr (PERT) xin = nl_load<T, false>(in_i, lsb, o + lsb);
+            xn = nl_load<T, FUSE == 1, O>(in, lsb, o + lsb, keepq != 0);
+            if constexpr (PERT) xin = nl_load<T, false, O>(in_i, lsb, o + lsb);
         }
         NLIn<T> x = xa;
         if constexpr (PERT) x = nl_perturb<T>(xa, xia, pf);
@@ -502,7 +504,7 @@ nl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
             acc[NL_OUT_FHPSL] += wlive * double(enthalpy_diff<T>(r.rfln, e.RLVTT, ref[NL_OUT_FHPSL]));
             acc[NL_OUT_FHPSN] += wlive * double(enthalpy_diff<T>(r.sfln, e.RLSTT, ref[NL_OUT_FHPSN]));
         } else {
-            if (live) nl_store<T>(out, e, lsb, o, r);
+            if (live) nl_store<T, O>(out, e, lsb, o, r);
             if constexpr (CS2_NL_DRAIN != 0) drain_vmem();
         }
         xa = xn;
@@ -822,7 +824,7 @@ nl_ring_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtr
             if (live) stg(qsat_out, o, x.qsat);   // an 11th store per level: not counted in NFULL (under-counting is safe)
         }
         const NLOut<T> r = nl_level<T, EVAP, LIN>(e, kc, xk, x, eta_k, scalm_k, crh, dt, aph_s, c);
-        if (live) nl_store<T>(out, e, lsb, o, r);
+        if (live) nl_store<T, uint32_t>(out, e, lsb, o, r);
         o += lsb;
         slot = slot + 1 == RD ? 0 : slot + 1;
         pslot = pslot + 1 == RD ? 0 : pslot + 1;
@@ -849,8 +851,9 @@ int launch_nl(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
     const T tpf = static_cast<T>(pf);
     const NLK<T> kc = make_nlk<T>(p, dt, evap);
     const ExpK<T> xk = make_expk<T>();
-    if (!fits_u32_offsets<T>(nz, ls)) return -2;
     const int fuse = qsat_out ? 1 : (in_i ? (partials ? 3 : 2) : 0);
+    const bool big = !fits_u32_offsets<T>(nz, ls);
+    if (big && fuse != 0) return -2;          // the fused build extensions keep 32-bit offsets
     const int keepq = qsat_fits_cache<T>(nz, ls) ? 1 : 0;   // in_qsat: default cache policy only when the field fits
     if (fuse == 1 && !p.LPHYLIN) return -2;   // only the LPHYLIN form of `saturation` is fused
 #define CS2_NL_LAUNCH(EV, LN, FU)                                                                                 \
@@ -874,7 +877,7 @@ int launch_nl(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
     // to 2 fp64 / 4 fp32 columns: `storage.zeros` pads the level pitch to 512 B); a partly filled last wave takes the
     // RAGGED instantiation
     constexpr int kNPL = RingGeom<T>::NPL;
-    bool ring = fuse <= 1 && nx > 0 && nz >= CS2_NL_RING && (ls * int64_t(sizeof(T))) % 16 == 0 &&
+    bool ring = !big && fuse <= 1 && nx > 0 && nz >= CS2_NL_RING && (ls * int64_t(sizeof(T))) % 16 == 0 &&
                 ls >= int64_t((nx + kNPL - 1) / kNPL) * kNPL;
     const bool ragged = nx % 64 != 0;
     for (int i = 0; i < NL_NUM_IN && ring; ++i)
@@ -934,6 +937,18 @@ int launch_nl(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
         return hipGetLastError() == hipSuccess ? 0 : -1;
     }
 #endif
+    if (big) {       // fields of 4 GiB and more: the register-path kernel with 64-bit offsets
+#define CS2_NL_BIG(EV, LN)                                                                                         \
+    hipLaunchKernelGGL((nl_kernel<T, EV, LN, sizeof(T) == 8, 0, true>), grid, block, smem, stream, e, kc, xk, nx,  \
+                       nz, ls, ci, eta, co, tdt, cii, tpf, qsat_out, partials, keepq)
+        if (evap && lin) CS2_NL_BIG(true, true);
+        else if (evap && !lin) CS2_NL_BIG(true, false);
+        else if (!evap && lin) CS2_NL_BIG(false, true);
+        else CS2_NL_BIG(false, false);
+#undef CS2_NL_BIG
+        note_kernel("cs2::nl_kernel<big>");
+        return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
     if (fuse == 0) CS2_NL_FLAGS(0);
     else if (fuse == 1) CS2_NL_FLAGS(1);
     else if (fuse == 2) CS2_NL_FLAGS(2);
@@ -1146,8 +1161,8 @@ nl_taylor_multi_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t 
 #ifndef CS2_NL_MULTI_COPYBUF
 #define CS2_NL_MULTI_COPYBUF 1
 #endif
-    NLIn<T> xa = nl_load<T, false>(in, lsb, colb), xb;
-    if constexpr (!INC) xb = nl_load<T, false>(in_i, lsb, colb);
+    NLIn<T> xa = nl_load<T, false, uint32_t>(in, lsb, colb), xb;
+    if constexpr (!INC) xb = nl_load<T, false, uint32_t>(in_i, lsb, colb);
     T xr[NL_NUM_OUT];
     nl_load_refs<T>(ref, lsb, colb, xr);
     uint32_t o = colb;
@@ -1157,8 +1172,8 @@ nl_taylor_multi_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t 
 #pragma unroll
         for (int f = 0; f < NL_NUM_OUT; ++f) nr[f] = xr[f];
         if (k + 1 < nz) {
-            na = nl_load<T, false>(in, lsb, o + lsb);
-            if constexpr (!INC) nb = nl_load<T, false>(in_i, lsb, o + lsb);
+            na = nl_load<T, false, uint32_t>(in, lsb, o + lsb);
+            if constexpr (!INC) nb = nl_load<T, false, uint32_t>(in_i, lsb, o + lsb);
             nl_load_refs<T>(ref, lsb, o + lsb, nr);
         }
         const T eta_k = s_eta[k], scalm_k = s_scalm[k];

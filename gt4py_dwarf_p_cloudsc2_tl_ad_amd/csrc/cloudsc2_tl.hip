@@ -29,8 +29,8 @@ struct TLIn {
     T ap, aph1, lu1, lude, mfd, mfu, q, qi, ql, qsat, supsat, t, tq, tqi, tql, tt;
 };
 
-template <typename T>
-__device__ __forceinline__ TLIn<T> tl_load(const CPtrs<T, NL_NUM_IN>& in, uint32_t lsb, uint32_t o) {
+template <typename T, typename O>
+__device__ __forceinline__ TLIn<T> tl_load(const CPtrs<T, NL_NUM_IN>& in, O lsb, O o) {
     TLIn<T> x;
     x.ap = ldg(in.p[NL_IN_AP], o);
     x.aph1 = ldg(in.p[NL_IN_APH], o + lsb);
@@ -538,9 +538,9 @@ __device__ __forceinline__ TLOut<T> tl_level(const Ext<T>& e, const NLK<T>& kc, 
     return o;
 }
 
-template <typename T>
+template <typename T, typename O>
 __device__ __forceinline__ void tl_store(const MPtrs<T, NL_NUM_OUT>& out, const MPtrs<T, NL_NUM_OUT>& out_i,
-                                         const Ext<T>& e, uint32_t lsb, uint32_t i, const TLOut<T>& o) {
+                                         const Ext<T>& e, O lsb, O i, const TLOut<T>& o) {
     stg(out.p[NL_OUT_CLC], i, o.clc);
     stg(out_i.p[NL_OUT_CLC], i, o.clc_i);
     stg(out.p[NL_OUT_COVPTOT], i, o.covptot);   // :185-186 (only the evaporation block sets it non-zero)
@@ -566,7 +566,8 @@ __device__ __forceinline__ void tl_store(const MPtrs<T, NL_NUM_OUT>& out, const 
 
 // INC: the perturbation fields are not read but formed as finc * in (state_increment fused in, see tl_increment):
 // 16 input streams instead of 32, no landing buffer for the second 16.
-template <typename T, bool REG, bool EVAP, bool INC = false>
+// BIG: 64-bit byte offsets (fields of 4 GiB and more, see offset_t in cloudsc2_common.hpp); instantiated without INC only.
+template <typename T, bool REG, bool EVAP, bool INC = false, bool BIG = false>
 __global__ void __launch_bounds__(kColBlock)
 tl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, NL_NUM_IN> in,
           CPtrs<T, NL_NUM_IN> in_i, const T* __restrict__ eta, MPtrs<T, NL_NUM_OUT> out, MPtrs<T, NL_NUM_OUT> out_i,
@@ -593,27 +594,28 @@ tl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
     // then drains every store of a level (`s_waitcnt vmcnt(0)`) before the next level's words are handed over
     // (docs/TUNING_LOG.md 3.9).
     if (gcol >= nx) return;
+    using O = offset_t<BIG>;
 #if CS2_TL_DIAG == 2
-    const uint32_t lsb = nz < 0 ? uint32_t(ls) : 0u;   // diagnostics only (wrong results): every level reads and writes level 0 -
+    const O lsb = nz < 0 ? O(ls) : O(0);   // diagnostics only (wrong results): every level reads and writes level 0 -
 #else                                                  // cache-resident rows, the kernel's time without HBM
-    const uint32_t lsb = uint32_t(ls) * uint32_t(sizeof(T));
+    const O lsb = O(ls) * O(sizeof(T));
 #endif
-    const uint32_t colb = uint32_t(gcol) * uint32_t(sizeof(T));
+    const O colb = O(gcol) * O(sizeof(T));
 
-    const T trpaus = trpaus_prescan<T>(in.p[NL_IN_T], in.p[NL_IN_TND_CML_T], lsb, colb, dt, s_eta, klo, khi);
+    const T trpaus = trpaus_prescan<T, false, O>(in.p[NL_IN_T], in.p[NL_IN_TND_CML_T], lsb, colb, dt, s_eta, klo, khi);
     const CrhCol<T> crh = crh_setup<T>(trpaus);
 
     // :124-135
     TLCarry<T> c;
     c.rfl = c.rfl_i = c.sfl = c.sfl_i = c.covptot = c.covptot_i = T(0.0);
     c.aph_k = ldg(in.p[NL_IN_APH], colb);
-    c.aph_s = EVAP ? ldg(in.p[NL_IN_APH], uint32_t(nz) * lsb + colb) : T(1.0);
+    c.aph_s = EVAP ? ldg(in.p[NL_IN_APH], O(nz) * lsb + colb) : T(1.0);
     if constexpr (INC) {
         c.aph_k_i = rounded_product<T>(finc, c.aph_k);
         c.aph_s_i = EVAP ? rounded_product<T>(finc, c.aph_s) : T(0.0);
     } else {
         c.aph_k_i = ldg(in_i.p[NL_IN_APH], colb);
-        c.aph_s_i = EVAP ? ldg(in_i.p[NL_IN_APH], uint32_t(nz) * lsb + colb) : T(0.0);
+        c.aph_s_i = EVAP ? ldg(in_i.p[NL_IN_APH], O(nz) * lsb + colb) : T(0.0);
     }
 
     // :757-765
@@ -626,29 +628,29 @@ tl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
     stg(out.p[NL_OUT_FHPSN], colb, T(0.0));
     stg(out_i.p[NL_OUT_FHPSN], colb, T(0.0));
 
-    uint32_t o = colb;
+    O o = colb;
     if constexpr (INC) {
-        TLIn<T> xa = tl_load<T>(in, lsb, o);
+        TLIn<T> xa = tl_load<T, O>(in, lsb, o);
         for (int k = 0; k < nz; ++k) {
             TLIn<T> xn = xa;
-            if (k + 1 < nz) xn = tl_load<T>(in, lsb, o + lsb);
+            if (k + 1 < nz) xn = tl_load<T, O>(in, lsb, o + lsb);
             const TLIn<T> ya = tl_increment<T>(xa, finc, zero_supsat_i != 0);
             const TLOut<T> r = tl_level<T, REG, EVAP>(e, kc, xk, xa, ya, k, s_eta[k], s_scalm[k], crh, dt, c);
-            tl_store<T>(out, out_i, e, lsb, o, r);
+            tl_store<T, O>(out, out_i, e, lsb, o, r);
             if constexpr (CS2_TL_DRAIN != 0) drain_vmem<CS2_TL_DRAIN_LEFT>();
             xa = xn;
             o += lsb;
         }
     } else {
-        TLIn<T> xa = tl_load<T>(in, lsb, o), ya = tl_load<T>(in_i, lsb, o);
+        TLIn<T> xa = tl_load<T, O>(in, lsb, o), ya = tl_load<T, O>(in_i, lsb, o);
         for (int k = 0; k < nz; ++k) {
             TLIn<T> xn = xa, yn = ya;
             if (k + 1 < nz) {
-                xn = tl_load<T>(in, lsb, o + lsb);
-                yn = tl_load<T>(in_i, lsb, o + lsb);
+                xn = tl_load<T, O>(in, lsb, o + lsb);
+                yn = tl_load<T, O>(in_i, lsb, o + lsb);
             }
             const TLOut<T> r = tl_level<T, REG, EVAP>(e, kc, xk, xa, ya, k, s_eta[k], s_scalm[k], crh, dt, c);
-            tl_store<T>(out, out_i, e, lsb, o, r);
+            tl_store<T, O>(out, out_i, e, lsb, o, r);
             if constexpr (CS2_TL_DRAIN != 0) drain_vmem<CS2_TL_DRAIN_LEFT>();
             xa = xn;
             ya = yn;
@@ -875,7 +877,7 @@ tl_ring_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtr
         tl_ring_read16<63>(a + YOFF, y);      // same level, already covered by the wait above (63 = no further wait)
         tl_table_read(ta, ta + tb_off, eta_k, scalm_k);
         const TLOut<T> r = tl_level<T, REG, EVAP>(e, kc, xk, x, y, k, eta_k, scalm_k, crh, dt, c);
-        tl_store<T>(out, out_i, e, lsb, o, r);
+        tl_store<T, uint32_t>(out, out_i, e, lsb, o, r);
         o += lsb;
         slot = slot + 1 == RD ? 0 : slot + 1;
         pslot = pslot + 1 == RD ? 0 : pslot + 1;
@@ -900,7 +902,21 @@ int launch_tl(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
     const T tdt = static_cast<T>(dt);
     const NLK<T> kc = make_nlk<T>(p, dt, evap);
     const ExpK<T> xk = make_expk<T>();
-    if (!fits_u32_offsets<T>(nz, ls)) return -2;
+    const bool big = !fits_u32_offsets<T>(nz, ls);
+    if (big) {       // fields of 4 GiB and more: the register-path kernel with 64-bit offsets (not the fused-increment variant)
+        if (inc) return -2;
+#define CS2_TL_BIG(REG, EVAP)                                                                                      \
+    hipLaunchKernelGGL((tl_kernel<T, REG, EVAP, false, true>), grid, block, smem, stream, e, kc, xk, nx, nz, ls,   \
+                       ci, cii, eta, co, coi, tdt, tinc, zsi)
+        if (p.LREGCL) {
+            if (evap) CS2_TL_BIG(true, true); else CS2_TL_BIG(true, false);
+        } else {
+            if (evap) CS2_TL_BIG(false, true); else CS2_TL_BIG(false, false);
+        }
+#undef CS2_TL_BIG
+        note_kernel("cs2::tl_kernel<big>");
+        return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
     constexpr int kRing = sizeof(T) == 8 ? CS2_TL_RING : CS2_TL_RING_F32;
     if constexpr (kRing >= 2) {
         // LDS-ring variant: whole waves, 16-byte aligned rows of every input field (the DMA moves 16 B per lane)

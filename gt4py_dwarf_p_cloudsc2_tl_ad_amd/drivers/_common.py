@@ -216,6 +216,9 @@ def tune_field_placement(field_dicts, objective, *, _any_device: bool = False, *
         objective()
 
     np_dtype = {torch.float64: np.float64, torch.float32: np.float32}[first.dtype]
+    import time
+
+    t_tune = time.perf_counter()
     try:
         fields, report = storage.tune_placement(nx, nz, np_dtype, first.device, order, sources, launch, **tuner_kw)
     except Exception as exc:  # noqa: BLE001 - e.g. out of memory, "do not fit the arena cap", a failing objective
@@ -230,6 +233,7 @@ def tune_field_placement(field_dicts, objective, *, _any_device: bool = False, *
         return {"fields": len(groups), "error": f"{type(exc).__name__}: {exc}"[:300]}
     point_at(fields)
     report["fields"] = len(groups)
+    report["tuning_s"] = time.perf_counter() - t_tune
     return report
 
 
@@ -239,7 +243,15 @@ def report_placement(rep: Dict[str, Any], unit: str = "run") -> None:
         print(f"[cloudsc2-hip] field placement NOT tuned ({rep['error']}): the {rep.get('fields')} fields stay where they "
               "were, the run continues on the untuned placement")
         return
-    print(f"[cloudsc2-hip] field placement tuned over {rep.get('candidates')} candidates: "
-          f"{rep.get('default_ms', 0):.4f} -> {rep.get('tuned_ms', 0):.4f} ms per {unit} "
-          f"(+{rep.get('extra_spacing_x2MB')} x 2 MB slab spacing, stagger {rep.get('stagger_bytes')} B, "
-          f"shift {rep.get('shift_MB')} MB, {rep.get('fields')} fields)")
+    # BOTH figures, always: what the same timed region takes on the untuned placement and on the tuned one, and what the
+    # opt-in cost (the arena stays allocated as long as the fields live; the tuning time is outside the timed runs)
+    st2 = rep.get("second_stage")
+    stage = ("" if st2 is None else
+             f"; second stage {'chosen' if st2.get('chosen') else 'searched, not chosen'}"
+             f" ({st2.get('candidates')} candidates at shifts up to {st2.get('shift_MB')} MB)" if "error" not in st2 else
+             f"; second stage skipped ({st2['error']})")
+    print(f"[cloudsc2-hip] field placement: UNTUNED {rep.get('default_ms', 0):.4f} ms per {unit} -> TUNED "
+          f"{rep.get('tuned_ms', 0):.4f} ms per {unit} ({100.0 * (1.0 - rep.get('tuned_ms', 0) / max(rep.get('default_ms', 0), 1e-30)):+.1f} % "
+          f"faster; {rep.get('candidates')} candidates, +{rep.get('extra_spacing_x2MB')} x 2 MB slab spacing, stagger "
+          f"{rep.get('stagger_bytes')} B, shift {rep.get('shift_MB')} MB, {rep.get('fields')} fields; cost: a "
+          f"{rep.get('arena_bytes', 0) / 1e9:.1f} GB arena and {rep.get('tuning_s', 0):.1f} s of tuning{stage})")

@@ -45,8 +45,10 @@ extern "C" {
 
 #define CLOUDSC2_OK 0
 #define CLOUDSC2_E_ARG (-1)      /* bad argument (null pointer, nx/nz/stride out of range)      */
-#define CLOUDSC2_E_UNSUPPORTED (-2) /* no kernel for this call: ICALL != 0, or a field of 4 GiB or more
-                                       ((nz+1) * lev_stride * sizeof(element) must be < 2^32 for the column kernels) */
+#define CLOUDSC2_E_UNSUPPORTED (-2) /* no kernel for this call: ICALL != 0, or a FUSED build extension (cloudsc2_nl_fused_*,
+                                       _nl_taylor*, _tl_incremented_*) on fields of 4 GiB or more ((nz+1) * lev_stride *
+                                       sizeof(element) must be < 2^32 there).  cloudsc2_nl / _tl / _ad themselves take
+                                       fields of any size: beyond 4 GiB they run their 64-bit-offset instantiation */
 #define CLOUDSC2_E_LAUNCH (-3)   /* HIP reported an error at launch                              */
 #define CLOUDSC2_E_NODEVICE (-4) /* no HIP device visible                                        */
 

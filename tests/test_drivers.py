@@ -400,7 +400,7 @@ def test_nonlinear_driver_with_tuned_field_placement(gpu, capsys):
     a = run_nonlinear.main(base)
     b = run_nonlinear.main(base + ["--tune-placement"])
     out = capsys.readouterr().out
-    assert "field placement tuned over" in out and b["placement"]["fields"] >= 26
+    assert "field placement: UNTUNED" in out and " -> TUNED " in out and "cost: a " in out and b["placement"]["fields"] >= 26
     assert b["placement"]["tuned_ms"] <= b["placement"]["default_ms"]
     for d in ("tends", "diags"):
         for k, v in a[d].items():
@@ -419,12 +419,12 @@ def test_taylor_and_symmetry_drivers_with_tuned_field_placement(gpu, capsys):
     a = run_taylor_test.main(base)
     b = run_taylor_test.main(base + ["--tune-placement"])
     out = capsys.readouterr().out
-    assert out.count("field placement tuned over") == 1 and b["placement"]["fields"] >= 80
+    assert out.count("field placement: UNTUNED") == 1 and b["placement"]["fields"] >= 80
     assert np.array_equal(a["norms"], b["norms"]) and a["passed"] == b["passed"]
     c = run_symmetry_test.main(base)
     d = run_symmetry_test.main(base + ["--tune-placement"])
     out = capsys.readouterr().out
-    assert out.count("field placement tuned over") == 1 and d["placement"]["fields"] >= 70
+    assert out.count("field placement: UNTUNED") == 1 and d["placement"]["fields"] >= 70
     assert c["passed"] == d["passed"] and c["detail"] == d["detail"]
     for k, v in c["state"].items():
         if hasattr(v, "data") and isinstance(v.data, torch.Tensor):

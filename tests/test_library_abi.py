@@ -81,8 +81,10 @@ def test_stencil_rejects_cpu_tensors(hip_lib):
 
 
 def test_size_limits_and_empty_calls(hip_lib):
-    """Edge sizes are settled on the host, before any launch: a field beyond 4 GiB (32-bit byte offsets inside a field)
-    is refused with CLOUDSC2_E_UNSUPPORTED and a message that says what to do; nx = 0 is a successful no-op."""
+    """Edge sizes are settled on the host, before any launch.  Fields beyond 4 GiB (r04): the plain stencils accept them
+    (their 64-bit-offset instantiation; without a GPU the call then ends in a launch / no-device error, never in
+    CLOUDSC2_E_UNSUPPORTED), the fused build extensions keep 32-bit byte offsets and refuse them with a message that says
+    what to do; nx = 0 is a successful no-op."""
     from gt4py_dwarf_p_cloudsc2_tl_ad_amd import _lib
     from gt4py_dwarf_p_cloudsc2_tl_ad_amd.params import default_externals, make_params
 
@@ -90,12 +92,18 @@ def test_size_limits_and_empty_calls(hip_lib):
     ins, ins_i = _lib.ptr_array([4096] * 16), _lib.ptr_array([4096] * 16)      # never dereferenced on these paths
     outs, outs_i = _lib.ptr_array([4096] * 10), _lib.ptr_array([4096] * 10)
     big = 4_000_000                                                              # x 138 levels x 8 B > 2^32
-    assert hip_lib.cloudsc2_nl_f64(ctypes.byref(p), big, 137, big, ins, 4096, outs, 3600.0, None) == -2
-    assert "2^32" in _lib.last_error()
-    assert hip_lib.cloudsc2_tl_f64(ctypes.byref(p), big, 137, big, ins, ins_i, 4096, outs, outs_i, 3600.0, None) == -2
-    assert hip_lib.cloudsc2_ad_f64(ctypes.byref(p), big, 137, big, ins, outs, 4096, outs, ins_i, 3600.0, None) == -2
+    import torch
+
+    if not torch.cuda.is_available():      # (with a GPU these would really launch on the dummy pointers)
+        assert hip_lib.cloudsc2_nl_f64(ctypes.byref(p), big, 137, big, ins, 4096, outs, 3600.0, None) not in (0, -2)
+        assert hip_lib.cloudsc2_tl_f64(ctypes.byref(p), big, 137, big, ins, ins_i, 4096, outs, outs_i, 3600.0, None) not in (0, -2)
+        assert hip_lib.cloudsc2_ad_f64(ctypes.byref(p), big, 137, big, ins, outs, 4096, outs, ins_i, 3600.0, None) not in (0, -2)
+    # perturbed_state fused into NL, state_increment fused into TL: 32-bit offsets, refused before anything is launched
+    assert hip_lib.cloudsc2_nl_fused_f64(ctypes.byref(p), big, 137, big, ins, ins_i, 0.01, None, 4096, outs, 3600.0, None) == -2
+    assert "2^32" in _lib.last_error() and "cloudsc2_nl / _tl / _ad have no such limit" in _lib.last_error()
+    assert hip_lib.cloudsc2_tl_incremented_f64(ctypes.byref(p), big, 137, big, ins, 0.01, 4096, outs, outs_i, 3600.0, None) == -2
     with pytest.raises(ValueError, match="2\\^32"):
-        _lib.check(-2, "cloudsc2_nl")
+        _lib.check(-2, "cloudsc2_nl_fused")
     # fp32 halves the footprint: the same shape is accepted by the size check (and would launch on a GPU)
     for fn, args in (("cloudsc2_nl_f64", (ins, 4096, outs, 3600.0, None)),
                      ("cloudsc2_tl_f64", (ins, ins_i, 4096, outs, outs_i, 3600.0, None)),

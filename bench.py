@@ -32,7 +32,7 @@ line and exits with the child's return code.
 
 Field placement: before anything is timed, `storage.tune_placement` measures where the 26 fields of the step should sit in
 HBM for this process (same kernels, same arguments, bit-identical results; the spacing between the fields' starting
-addresses decides how 26 concurrent streams fall onto HBM channels and banks, worth up to 10 %) and the
+addresses decides how 26 concurrent streams fall onto HBM channels and banks, worth up to 10 %, docs/TUNING_LOG.md 3.7) and the
 state is placed there; `--placement separate` gives one torch allocation per field instead.  The record says what was done
 (`placement`).
 
@@ -793,7 +793,7 @@ def main(argv=None):
 
     # Placement of the step's 26 fields in HBM (gt4py_dwarf_p_cloudsc2_tl_ad_amd/storage.py: FieldArena, tune_placement).
     # The kernels, their arguments and their results are the same for every placement; what changes is how the 26
-    # concurrent streams fall onto HBM channels and banks.
+    # concurrent streams fall onto HBM channels and banks (docs/TUNING_LOG.md 3.7).
     order = ["in_" + n for n in NL_IN] + ["out_" + n for n in NL_OUT]
     sources = {"in_" + k[2:]: v for k, v in s.items()}
     placement = {"mode": args.placement}
@@ -1143,8 +1143,9 @@ def main(argv=None):
         # the full report of ONE rank; a rank that skipped the tuner or fell back to plain allocations shows here)
         res["per_rank_placement"] = rank_reports
         res["startup_s_max_over_ranks"] = max(r["startup_s"]["to_first_step_s"] for r in rank_reports)
-        if default_placement is None and placement.get("chosen", "").startswith("plain"):
-            # the timed region itself ran on plain allocations (they beat the tuner's winner): the two figures coincide
+        if default_placement is None and placement.get("mode") == "separate":
+            # the timed region itself ran on plain allocations (asked for, or they beat the tuner's winner, or the tuner
+            # failed / was skipped): the two figures coincide
             res["value_default_placement"] = res["value"]
             res["ms_per_step_default_placement"] = res["ms_per_step"]
             res["default_placement_is_value"] = True

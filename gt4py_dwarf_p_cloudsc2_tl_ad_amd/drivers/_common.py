@@ -180,7 +180,7 @@ def tune_field_placement(field_dicts, objective, *, _any_device: bool = False, *
     """Re-place every 3-D GPU field found in `field_dicts` (dicts name -> DataArray; a field shared by several dicts or
     DataArrays is one field) at the placement `storage.tune_placement` measures to be fastest for `objective()` - the
     caller's own timed region, run on the candidate placement.  Contents are preserved; the DataArrays are re-pointed at
-    the new storages in place, so every dict keeps working.  Returns the tuner's report.
+    the new storages in place, so every dict keeps working.  Returns the tuner's report (docs/TUNING_LOG.md 3.7).
     Exception-safe: if the tuner or the objective raises (out of memory, no room for the arena, a failing stencil), every
     DataArray is pointed back at its original storage with its original contents and the report carries `error` - the
     caller goes on untuned, as bench.py does.  (`_any_device`: lets the CPU unit test drive this with host tensors.)"""

@@ -34,7 +34,7 @@ def core(args):
         cloudsc2_nl(state, dt, out_tendencies=tends, out_diagnostics=diags)
 
     if args.tune_placement:
-        # build extension: where the ~26 fields of the timed region sit in HBM is measured and fixed for
+        # build extension (docs/TUNING_LOG.md 3.7): where the ~26 fields of the timed region sit in HBM is measured and fixed for
         # this process, with the timed region itself as the objective; contents and results are unchanged
         saved = cfg.gt4py_config.exec_info
         cfg.gt4py_config.exec_info = None

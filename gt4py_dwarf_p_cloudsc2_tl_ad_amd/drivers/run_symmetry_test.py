@@ -20,7 +20,7 @@ def core(args):
     if args.output_csv_file_stencils is not None and not args.graph:
         cfg.gt4py_config.reset_exec_info()                    # run_symmetry_test.py:92: per-stencil HIP events from here on
     if args.tune_placement:
-        # build extension: the ~80 fields of the test are re-placed in HBM where a whole run is fastest
+        # build extension (docs/TUNING_LOG.md 3.7): the ~80 fields of the test are re-placed in HBM where a whole run is fastest
         # (a captured HIP graph holds the OLD field addresses: candidates are timed eagerly, the graph is captured afterwards)
         graph, st.graph, st._graphed = st.graph, False, None
         try:
@@ -64,7 +64,7 @@ def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__)
     add_common_options(ap)
     ap.add_argument("--ad-traj-fix", action="store_true",
-                    help="use the AD kernel whose freezing tests match NL/TL (build extension, DESIGN.md 3.3)")
+                    help="use the AD kernel whose freezing tests match NL/TL (build extension, docs/DESIGN_r03_detail.md 3.3)")
     ap.add_argument("--fused", action="store_true",
                     help="timed call: state_increment fused into cloudsc2_tl (build extension cloudsc2_tl_incremented)")
     ap.add_argument("--graph", action="store_true",

@@ -22,7 +22,7 @@ def core(args):
     if args.output_csv_file_stencils is not None and not args.graph:
         cfg.gt4py_config.reset_exec_info()                    # run_taylor_test.py:93: per-stencil HIP events from here on
     if args.tune_placement:
-        # build extension: the ~90 fields of the test are re-placed in HBM where a whole run is fastest
+        # build extension (docs/TUNING_LOG.md 3.7): the ~90 fields of the test are re-placed in HBM where a whole run is fastest
         # (a captured HIP graph holds the OLD field addresses: candidates are timed eagerly and the graph is re-captured
         # on the fields' final placement)
         graph, tt.graph, tt._graphed = tt.graph, False, None

@@ -352,7 +352,7 @@ class SymmetryTest:
         if not ok:
             print(f"  ({self.last['columns_passing']} of {self.last['columns']} columns pass; the others are columns "
                   "whose saturation adjustment crosses RTT, where the reference's AD differs from its TL - "
-                  "DESIGN.md 3.3, quirks Q4/Q5)")
+                  "docs/DESIGN_r03_detail.md 3.3, quirks Q4/Q5)")
         return ok
 
     def _stencils(self, state, timestep: timedelta, enable_validation: bool) -> Optional[torch.Tensor]:

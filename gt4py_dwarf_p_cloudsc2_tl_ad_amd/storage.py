@@ -10,7 +10,7 @@ All 3-D storages have nz+1 levels, as in the reference (every kernel runs on
 ``domain=(nx, 1, nz+1)``, nonlinear/microphysics.py:168-169); K-vectors (`f_eta`, `klevel`) have nz+1
 entries too.
 
-Placement in HBM (`FieldArena`, `tune_placement`).  A stencil call streams 26 (NL) to 72 (AD) fields
+Placement in HBM (`FieldArena`, `tune_placement`; docs/TUNING_LOG.md 3.7).  A stencil call streams 26 (NL) to 72 (AD) fields
 concurrently, every wave touching the same (level, column) offset of each of them at about the same time, so how the
 fields' starting addresses relate decides how those requests fall onto HBM channels, banks and rows.  Measured with the
 kernels unchanged (profiles/r02/placement_*.txt, layout_scan*.txt): the same fields run cloudsc2_nl anywhere between 295

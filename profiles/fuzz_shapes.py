@@ -95,7 +95,7 @@ def main():
                                                               f"sums {s1[np.unravel_index(dev_f.argmax(), dev_f.shape)]!r}, mag {mag}")
         if dtype == np.float64 and not evap:
             # TL with general increments, AD with general forcings, every column on its own scale.  (The evaporation
-            # block's perturbations are ill-conditioned by construction - the reference's dt**2 quirk, DESIGN 3.3 - and on
+            # block's perturbations are ill-conditioned by construction - the reference's dt**2 quirk, docs/DESIGN_r03_detail.md 3.3 - and on
             # the coarse random grids of this fuzz even at dt = 60 s; tests/ pins that block on the 137-level grid.)
             tdt = dt
             fi = {k + "_i": v * rng.uniform(-0.02, 0.02, size=v.shape) for k, v in fields.items()}

@@ -312,3 +312,19 @@ def test_config5_whole_problem_on_one_gpu(gpu):
     assert d4["config"]["columns_total"] == 4194304 and len(d4["per_rank_ms"]) == 4 and d4["outputs_finite"] is True
     for name, v1 in d["validation_norm"].items():
         assert d4["validation_norm"][name] == pytest.approx(v1, rel=1e-9, abs=1e-300), name
+
+
+@pytest.mark.gpu
+def test_a_rank_that_started_too_slowly_skips_the_tuner_and_says_so(gpu):
+    """start-up is bounded - a rank that needed longer than `--startup-budget-s` to reach the placement
+    tuner (a cold node paging in torch, eight ranks queueing for the build lock) runs on plain allocations, and the record
+    says so for that rank; here the budget is 0 s, so the one rank must skip."""
+    p = _run("--steps", "3", "--warmup", "1", "--cols", "8192", "--cpu-cols", "0", "--no-extra-rooflines",
+             "--startup-budget-s", "0")
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.strip()][0])
+    assert d["placement"]["mode"] == "separate" and "--startup-budget-s 0" in d["placement"]["tune_skipped"]
+    r0 = d["per_rank_placement"][0]
+    assert r0["mode"] == "separate" and "skipped" in r0["chosen"] and r0["startup_s"]["tune_s"] == 0.0
+    assert d["value"] > 0 and d["value_default_placement"] == d["value"] and d["default_placement_is_value"] is True
+    assert "[bench] rank 0: import" in p.stderr

@@ -501,7 +501,7 @@ def test_tl_lds_ring_and_register_prefetch_paths_agree(gpu, dtype, nz, sw):
     ext = externals(NLEV=nz, **sw)
     fields, eta, dt = nl_case(nx, nz=nz, dtype=dtype, seed=5)
     if sw.get("LEVAPLS2"):
-        dt = 60.0        # the evaporation block amplifies rounding noise at 3600 s
+        dt = 60.0        # the evaporation block amplifies rounding noise at 3600 s (docs/DESIGN_r03_detail.md 3.3)
     fi = increments(fields, 0.01)
     want, want_i = run_oracle_tl(fields, fi, eta, dt, ext)
     tl = compile_stencil("cloudsc2_tl", ext)

@@ -1,4 +1,4 @@
-"""`storage.FieldArena` / `storage.tune_placement`: WHERE the fields of a call sit in HBM.  Placement never
+"""`storage.FieldArena` / `storage.tune_placement`: WHERE the fields of a call sit in HBM (docs/TUNING_LOG.md 3.7).  Placement never
 changes results - the GPU test holds a tuned placement bit-equal to separately allocated fields - only how the 26+ concurrent
 streams of a call fall onto HBM channels and banks."""
 import numpy as np

@@ -1092,11 +1092,75 @@ __device__ __forceinline__ void acc_wait(double (&v)[NL_NUM_OUT]) {
                    "+v"(v[9]));
 }
 
+// Kernel arguments as ONE struct (kernarg offset 0): the 42 field pointers are read from the kernarg segment at their point
+// of use (KernArgs in cloudsc2_common.hpp) instead of living in - and being spilled from - SGPRs.  This kernel is bound by
+// its VALU instructions, and 384 of the 3 996 of a level (NF = 5, fp64) were v_readlane_b32 fetching spilled SGPRs back.
+template <typename T, int NF>
+struct NLMArgs {
+    Ext<T> e;
+    NLK<T> kc;
+    ExpK<T> xk;
+    int nx, nz;
+    int64_t ls;
+    CPtrs<T, NL_NUM_IN> in, in_i;
+    CPtrs<T, NL_NUM_OUT> ref;
+    const T* eta;
+    T dt;
+    PFs<T, NF> pf;
+    double* partials;
+    int nf_total, f0;
+    T finc;
+    int zero_supsat_i;
+};
+#ifndef CS2_NL_MULTI_KARG
+#define CS2_NL_MULTI_KARG 1   // 1: field pointers are re-read from the kernarg segment (scalar loads) on every level
+#endif
+
 template <typename T, bool EVAP, bool LIN, bool PINK, int NF, bool INC>
 __global__ void __launch_bounds__(kColBlock, 1)
-nl_taylor_multi_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, NL_NUM_IN> in,
-                       CPtrs<T, NL_NUM_IN> in_i, CPtrs<T, NL_NUM_OUT> ref, const T* __restrict__ eta, T dt, PFs<T, NF> pf,
-                       double* __restrict__ partials, int nf_total, int f0, T finc, int zero_supsat_i) {
+nl_taylor_multi_kernel(const NLMArgs<T, NF> A) {
+    Ext<T> e = A.e;
+    NLK<T> kc = A.kc;
+    ExpK<T> xk = A.xk;
+    const int nx = A.nx, nz = A.nz, nf_total = A.nf_total, f0 = A.f0, zero_supsat_i = A.zero_supsat_i;
+    const int64_t ls = A.ls;
+    const T* __restrict__ eta = A.eta;
+    T dt = A.dt;
+    const PFs<T, NF> pf = A.pf;
+    double* __restrict__ partials = A.partials;
+    const T finc = A.finc;
+    KernArgs<NLMArgs<T, NF>> K;
+    const auto P_in = [&](int i) -> const T* { return K->in.p[i]; };
+    const auto P_ini = [&](int i) -> const T* { return K->in_i.p[i]; };
+    const auto P_ref = [&](int i) -> const T* { return K->ref.p[i]; };
+    // the 16 words of a level through a pointer source (nl_load's statement order)
+    const auto load16 = [&](const auto& ptr, uint32_t lsb_, uint32_t o_) {
+        NLIn<T> x;
+        x.ap = ldg(ptr(NL_IN_AP), o_);
+        x.aph1 = ldg(ptr(NL_IN_APH), o_ + lsb_);
+        x.lu1 = ldg(ptr(NL_IN_LU), o_ + lsb_);
+        x.lude = ldg(ptr(NL_IN_LUDE), o_);
+        x.mfd = ldg(ptr(NL_IN_MFD), o_);
+        x.mfu = ldg(ptr(NL_IN_MFU), o_);
+        x.q = ldg(ptr(NL_IN_Q), o_);
+        x.qi = ldg(ptr(NL_IN_QI), o_);
+        x.ql = ldg(ptr(NL_IN_QL), o_);
+        x.qsat = ldg(ptr(NL_IN_QSAT), o_);
+        x.supsat = ldg(ptr(NL_IN_SUPSAT), o_);
+        x.t = ldg(ptr(NL_IN_T), o_);
+        x.tq = ldg(ptr(NL_IN_TND_CML_Q), o_);
+        x.tqi = ldg(ptr(NL_IN_TND_CML_QI), o_);
+        x.tql = ldg(ptr(NL_IN_TND_CML_QL), o_);
+        x.tt = ldg(ptr(NL_IN_TND_CML_T), o_);
+        return x;
+    };
+    const auto load_refs = [&](uint32_t lsb_, uint32_t o_, T (&r)[NL_NUM_OUT]) {
+#pragma unroll
+        for (int f = 0; f < NL_NUM_OUT; ++f) {
+            const bool half = f == NL_OUT_FPLSL || f == NL_OUT_FPLSN || f == NL_OUT_FHPSL || f == NL_OUT_FHPSN;
+            r[f] = ldg(P_ref(f), half ? o_ + lsb_ : o_);
+        }
+    };
     extern __shared__ __align__(16) unsigned char smem_raw[];
     T* s_eta = reinterpret_cast<T*>(smem_raw);
     T* s_scalm = s_eta + (nz + 1);
@@ -1130,18 +1194,18 @@ nl_taylor_multi_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t 
     const uint32_t acc_addr = uint32_t(reinterpret_cast<uintptr_t>(s_acc));
     (void)acc_addr;
     T trpaus[NF];
-    trpaus_prescan_multi<T, NF, INC>(in.p[NL_IN_T], in.p[NL_IN_TND_CML_T], in_i.p[NL_IN_T], in_i.p[NL_IN_TND_CML_T], lsb, colb,
+    trpaus_prescan_multi<T, NF, INC>(P_in(NL_IN_T), P_in(NL_IN_TND_CML_T), P_ini(NL_IN_T), P_ini(NL_IN_TND_CML_T), lsb, colb,
                                      dt, s_eta, klo, khi, pf, finc, trpaus);
     CrhCol<T> crh[NF];
     NLCarry<T> c[NF];
     T aph_s[NF];
     {
-        const T aph0 = ldg(in.p[NL_IN_APH], colb);
-        const T aph0_i = INC ? rounded_product<T>(finc, aph0) : ldg(in_i.p[NL_IN_APH], colb);
+        const T aph0 = ldg(P_in(NL_IN_APH), colb);
+        const T aph0_i = INC ? rounded_product<T>(finc, aph0) : ldg(P_ini(NL_IN_APH), colb);
         T aphs = T(1.0), aphs_i = T(0.0);
         if constexpr (EVAP) {
-            aphs = ldg(in.p[NL_IN_APH], uint32_t(nz) * lsb + colb);
-            aphs_i = INC ? rounded_product<T>(finc, aphs) : ldg(in_i.p[NL_IN_APH], uint32_t(nz) * lsb + colb);
+            aphs = ldg(P_in(NL_IN_APH), uint32_t(nz) * lsb + colb);
+            aphs_i = INC ? rounded_product<T>(finc, aphs) : ldg(P_ini(NL_IN_APH), uint32_t(nz) * lsb + colb);
         }
 #pragma unroll
         for (int j = 0; j < NF; ++j) {
@@ -1161,20 +1225,23 @@ nl_taylor_multi_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t 
 #ifndef CS2_NL_MULTI_COPYBUF
 #define CS2_NL_MULTI_COPYBUF 1
 #endif
-    NLIn<T> xa = nl_load<T, false, uint32_t>(in, lsb, colb), xb;
-    if constexpr (!INC) xb = nl_load<T, false, uint32_t>(in_i, lsb, colb);
+    NLIn<T> xa = load16(P_in, lsb, colb), xb;
+    if constexpr (!INC) xb = load16(P_ini, lsb, colb);
     T xr[NL_NUM_OUT];
-    nl_load_refs<T>(ref, lsb, colb, xr);
+    load_refs(lsb, colb, xr);
     uint32_t o = colb;
     for (int k = 0; k < nz; ++k) {
+        // fp64 only: -4 ... -5 % there (2.24 -> 2.12 ms for the ten step sizes at 65 536 columns; bit-identical sums); in fp32 at
+        // 524 288 columns the kernel waits for HBM and the per-level scalar loads measured 0 ... +2 % (profiles/r04/ab_multi_*)
+        K.template fresh<(CS2_NL_MULTI_KARG != 0 && sizeof(T) == 8)>();
         NLIn<T> na = xa, nb = xb;
         T nr[NL_NUM_OUT];
 #pragma unroll
         for (int f = 0; f < NL_NUM_OUT; ++f) nr[f] = xr[f];
         if (k + 1 < nz) {
-            na = nl_load<T, false, uint32_t>(in, lsb, o + lsb);
-            if constexpr (!INC) nb = nl_load<T, false, uint32_t>(in_i, lsb, o + lsb);
-            nl_load_refs<T>(ref, lsb, o + lsb, nr);
+            na = load16(P_in, lsb, o + lsb);
+            if constexpr (!INC) nb = load16(P_ini, lsb, o + lsb);
+            load_refs(lsb, o + lsb, nr);
         }
         const T eta_k = s_eta[k], scalm_k = s_scalm[k];
         NLIn<T> inc_k;
@@ -1274,8 +1341,8 @@ int launch_nl_taylor_multi(const Cloudsc2Params& p, int nx, int nz, int64_t ls, 
         if (smem > size_t(64) * 1024 && !lds_opt_in(kern, attr_set, dev, smem)) return -1;                              \
         PFs<T, NFV> pf;                                                                                                 \
         for (int j = 0; j < NFV; ++j) pf.f[j] = static_cast<T>(pfs[f0 + j]);                                            \
-        hipLaunchKernelGGL(kern, grid, block, smem, stream, e, kc, xk, nx, nz, ls, ci, cii, cr, eta, tdt, pf, partials, \
-                           nf, f0, tinc, zsi);                                                                          \
+        const NLMArgs<T, NFV> margs = {e, kc, xk, nx, nz, ls, ci, cii, cr, eta, tdt, pf, partials, nf, f0, tinc, zsi};  \
+        hipLaunchKernelGGL(kern, grid, block, smem, stream, margs);                                                     \
     } while (0)
 #define CS2_NLM_FLAGS(NFV)                                            \
     do {                                                              \

@@ -328,3 +328,29 @@ def test_a_rank_that_started_too_slowly_skips_the_tuner_and_says_so(gpu):
     assert r0["mode"] == "separate" and "skipped" in r0["chosen"] and r0["startup_s"]["tune_s"] == 0.0
     assert d["value"] > 0 and d["value_default_placement"] == d["value"] and d["default_placement_is_value"] is True
     assert "[bench] rank 0: import" in p.stderr
+
+
+@pytest.mark.gpu
+def test_one_rank_under_torchrun_takes_the_rccl_path(gpu):
+    """The driver starts the N-rank bench as `python -m torch.distributed.run ... bench.py --gpus N`.  With ONE rank on the
+    box's one GPU that command runs the real RCCL code path end to end (two RCCL ranks cannot share a GPU): communicator
+    creation with its banner kept off stdout, barrier, the per-rank time / MAX / SUM all-reduces on device tensors,
+    `all_gather_object` of the rank reports, the rendezvous-store wait around rank 0's CPU baseline, the closing barrier."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), BENCH, "--gpus", "1", "--steps", "3", "--warmup", "1", "--cols", "8192",
+           "--no-extra-rooflines", "--cpu-cols", "256", "--cpu-budget-s", "0.3"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=e)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]               # the RCCL banner did not land on stdout
+    d = json.loads(lines[0])
+    assert d["collective_backend"] == "nccl (RCCL)" and d["rccl_ranks"] == 1 and d["n_gpus"] == 1
+    _nrank_record_is_complete(d, 1, real_kernels=True)
+    assert d["value"] > 0 and d["outputs_finite"] is True

@@ -27,10 +27,14 @@ NL_OUT = ("clc", "covptot", "fhpsl", "fhpsn", "fplsl", "fplsn", "tnd_q", "tnd_qi
 #       by libm-vs-ocml exp/tanh/pow (<= 1-2 ulp each), amplified through cancellations such as
 #       (qlwc - ql)/dt.  Errors are measured relative to the field's own scale:
 #       |a - b| <= RTOL * |b| + ATOL_REL * max|b|.
-# fp32: same with single-precision epsilons.
+# fp32: same with single-precision epsilons.  r04: 4 x tighter than the 2e-3 / 2e-4 of rounds 1-3.  Measured over the whole
+#       GPU suite: everything but three isolated `out_clc` points passes at 2e-4 / 2e-5 (clc = 1 - sqrt(...) amplifies a
+#       1-ulp difference of its argument to 2.3e-4 near the overcast threshold); worst cases by column scale are in
+#       profiles/r02/fp32_errors.txt (<= 2e-5), and the executed-reference vectors are held tighter still
+#       (tests/test_reference_exec_f32.py: 3e-5 / 1e-4 of a column's scale).
 TOL = {
     np.dtype("float64"): dict(rtol=1e-9, atol_rel=1e-11),
-    np.dtype("float32"): dict(rtol=2e-3, atol_rel=2e-4),
+    np.dtype("float32"): dict(rtol=5e-4, atol_rel=5e-5),
 }
 
 

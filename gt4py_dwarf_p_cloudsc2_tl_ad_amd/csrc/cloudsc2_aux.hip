@@ -16,6 +16,14 @@ constexpr int kAuxBlock = 256;
 #ifndef CS2_SAT_NT_STORE
 #define CS2_SAT_NT_STORE 0
 #endif
+// CS2_SAT_KEEP_LOADS (r04): with `keep`, in_ap / in_t are LOADED with the default cache policy too.  cloudsc2_nl reads the same
+// two fields right after (run_nonlinear.py:117-118); allocated in the 256 MB memory-side cache by this kernel's loads, they
+// are served from there to the NL kernel's (non-temporal) LDS-DMAs: inside the step cloudsc2_nl 329.5 -> 314.4 us, the step
+// 368.9 -> 349.9 us on plain allocations (profiles/r04/ab_keep_step*.txt).  Making the NL kernel's OWN ap / t DMAs cacheable
+// instead does the opposite (+5 %): each DMA carries a second field (aph, supsat) that then sweeps the cache.
+#ifndef CS2_SAT_KEEP_LOADS
+#define CS2_SAT_KEEP_LOADS 1
+#endif
 
 // MODE 0: LPHYLIN; MODE 1: not LPHYLIN, KFLAG == 1 (f_foeewmcu); MODE 2: not LPHYLIN, KFLAG != 1 (f_foeewm)
 template <typename T, int MODE>
@@ -26,7 +34,7 @@ saturation_kernel(Ext<T> e, ExpK<T> xk, int nx, int64_t ls, const T* __restrict_
     if (col >= nx) return;
     const int64_t i = int64_t(blockIdx.y) * ls + col;
     const T r = saturation_point<T, MODE>(e, xk, ntload(t + i), ntload(ap + i));
-    if (keep && !CS2_SAT_NT_STORE) qsat[i] = r;
+    if ((keep & 1) && !CS2_SAT_NT_STORE) qsat[i] = r;
     else ntstore(qsat + i, r);
 }
 
@@ -48,8 +56,13 @@ saturation_vec_kernel(Ext<T> e, ExpK<T> xk, int nxv, int nz, int64_t ls, const T
     for (int j = 0; j < kSatLPT; ++j) {
         const int k = k0 + j < nz ? k0 + j : nz - 1;
         const int64_t i = int64_t(k) * ls + int64_t(cv) * V;
-        va[j] = __builtin_nontemporal_load(reinterpret_cast<const vec_t*>(ap + i));
-        vt[j] = __builtin_nontemporal_load(reinterpret_cast<const vec_t*>(t + i));
+        if (CS2_SAT_KEEP_LOADS && (keep & 2)) {   // uniform: ap / t stay in the memory-side cache for the cloudsc2_nl that follows
+            va[j] = *reinterpret_cast<const vec_t*>(ap + i);
+            vt[j] = *reinterpret_cast<const vec_t*>(t + i);
+        } else {
+            va[j] = __builtin_nontemporal_load(reinterpret_cast<const vec_t*>(ap + i));
+            vt[j] = __builtin_nontemporal_load(reinterpret_cast<const vec_t*>(t + i));
+        }
     }
 #pragma unroll
     for (int j = 0; j < kSatLPT; ++j) {
@@ -58,7 +71,7 @@ saturation_vec_kernel(Ext<T> e, ExpK<T> xk, int nxv, int nz, int64_t ls, const T
 #pragma unroll
         for (int v = 0; v < V; ++v) r[v] = saturation_point<T, MODE>(e, xk, vt[j][v], va[j][v]);
         vec_t* dst = reinterpret_cast<vec_t*>(qsat + int64_t(k0 + j) * ls + int64_t(cv) * V);
-        if (keep && !CS2_SAT_NT_STORE) *dst = r;
+        if ((keep & 1) && !CS2_SAT_NT_STORE) *dst = r;
         else __builtin_nontemporal_store(r, dst);
     }
 }
@@ -69,7 +82,10 @@ int launch_saturation(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const
     const Ext<T> e = make_ext<T>(p);
     const ExpK<T> xk = make_expk<T>();
     constexpr int V = 16 / int(sizeof(T));
-    const int keep = qsat_fits_cache<T>(nz, ls) ? 1 : 0;
+    // bit 0: the qsat stores stay cacheable (the field fits beside the streams passing through); bit 1: the ap / t loads too
+    // (the three fields cloudsc2_nl shares with this kernel fit the 256 MB memory-side cache together)
+    const uint64_t field_bytes = uint64_t(nz + 1) * uint64_t(ls) * sizeof(T);
+    const int keep = (qsat_fits_cache<T>(nz, ls) ? 1 : 0) | (3 * field_bytes <= (uint64_t(240) << 20) ? 2 : 0);
     const bool vec = nx % V == 0 && (ls * int64_t(sizeof(T))) % 16 == 0 && reinterpret_cast<uintptr_t>(ap) % 16 == 0 &&
                      reinterpret_cast<uintptr_t>(t) % 16 == 0 && reinterpret_cast<uintptr_t>(qsat) % 16 == 0;
     if (vec) {

@@ -568,6 +568,11 @@ nl_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtrs<T, 
 #ifndef CS2_NL_QSAT_AUX
 #define CS2_NL_QSAT_AUX 0
 #endif
+// Which input fields (bit f = field NL_IN_*) take that policy: the DMA instruction that carries any of them does.  Default:
+// in_qsat only.  (A/B switch, r04: in_ap / in_t, which `saturation` read just before, measured in profiles/r04/ab_keep_*.)
+#ifndef CS2_NL_KEEP_FIELDS
+#define CS2_NL_KEEP_FIELDS (1 << NL_IN_QSAT)
+#endif
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef const __attribute__((address_space(1))) void* glb_void_ptr;
 
@@ -763,7 +768,7 @@ nl_ring_kernel(Ext<T> e, NLK<T> kc, ExpK<T> xk, int nx, int nz, int64_t ls, CPtr
 #pragma unroll
         for (int i = 0; i < G::NI; ++i) {
             // (the cache-policy operand must be a literal constant at each call site)
-            if (CS2_NL_QSAT_AUX >= 0 && keepq && i == NL_IN_QSAT / G::NPL)   // uniform
+            if (CS2_NL_QSAT_AUX >= 0 && keepq && ((CS2_NL_KEEP_FIELDS >> (i * G::NPL)) & ((1 << G::NPL) - 1)) != 0)   // uniform
                 __builtin_amdgcn_global_load_lds((glb_void_ptr)src[i],
                                                  (lds_void_ptr)(&smem_raw[ring0 + uint32_t(slot * G::SLOT + i * 1024)]),
                                                  16, 0, CS2_NL_QSAT_AUX >= 0 ? CS2_NL_QSAT_AUX : 0);

@@ -71,7 +71,13 @@ def main():
     pout = _lib.ptr_array([outs[n].data_ptr() for n in NL_OUT])
     stream = torch.cuda.current_stream().cuda_stream
 
+    step = int(opts.get("step", 0))      # --step=1: time the driver's step (saturation + cloudsc2_nl of the SAME library)
+
     def call(lib):
+        if step:
+            rc = getattr(lib, "cloudsc2_saturation_" + sfx)(ctypes.byref(p), nx, nz, ls, f["in_ap"].data_ptr(), f["in_t"].data_ptr(),
+                                                            f["in_qsat"].data_ptr(), stream)
+            assert rc == 0, rc
         rc = getattr(lib, "cloudsc2_nl_" + sfx)(ctypes.byref(p), nx, nz, ls, pin, eta.data_ptr(), pout, 3600.0, stream)
         assert rc == 0, rc
 
@@ -94,6 +100,24 @@ def main():
             b.record()
             torch.cuda.synchronize()
             times[name].append(a.elapsed_time(b) / 5)
+    if step:
+        # where a step's time goes: HIP events around each of the two launches of a 40-step train per library
+        for name, lib in libs.items():
+            evs = []
+            for _ in range(42):
+                e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+                e0.record()
+                rc = getattr(lib, "cloudsc2_saturation_" + sfx)(ctypes.byref(p), nx, nz, ls, f["in_ap"].data_ptr(),
+                                                                f["in_t"].data_ptr(), f["in_qsat"].data_ptr(), stream)
+                e1.record()
+                rc |= getattr(lib, "cloudsc2_nl_" + sfx)(ctypes.byref(p), nx, nz, ls, pin, eta.data_ptr(), pout, 3600.0, stream)
+                e2.record()
+                assert rc == 0
+                evs.append((e0, e1, e2))
+            torch.cuda.synchronize()
+            sat = np.median([a.elapsed_time(b) for a, b, _ in evs[2:]]) * 1e3
+            nl_ = np.median([b.elapsed_time(c) for _, b, c in evs[2:]]) * 1e3
+            print(f"{name:>12s}: inside the step  saturation {sat:6.1f} us   cloudsc2_nl {nl_:6.1f} us")
     bytes_ = 3567 * np.dtype(np_dtype).itemsize * nx
     for name, t in times.items():
         t = np.array(t)

@@ -14,7 +14,7 @@ python bench.py > $D/bench_default.json 2> $D/bench_default.err
 python bench.py --config 3 --steps 20 --warmup 5 > $D/bench_config3.json 2> $D/bench_config3.err
 python bench.py --config 4 --steps 20 --warmup 5 > $D/bench_config4.json 2> $D/bench_config4.err
 # the N-rank path with REAL kernels on this box's one GPU (gloo carries barrier + reductions; at most 6 processes may have the GPU open, the launcher included: 4 ranks)
-python bench.py --gpus 4 --collective gloo --steps 20 --warmup 5 --cpu-cols 0 --no-extra-rooflines > $D/bench_rehearsal_4ranks_one_gpu.json 2> $D/bench_rehearsal_4ranks.err
+python bench.py --gpus 4 --collective gloo --steps 20 --warmup 5 --cpu-cols 2048 --cpu-budget-s 1 --no-extra-rooflines > $D/bench_rehearsal_4ranks_one_gpu.json 2> $D/bench_rehearsal_4ranks.err
 # (the 8-rank dry run needs no GPU and is taken in the build container: `python bench.py --gpus 8 --dry-run`; on a GPU box
 #  its nine processes map the HIP runtime and can trip the pool's limit of 6 processes per GPU)
 fi

@@ -305,18 +305,22 @@ def gather_rank_reports(dist, world, report):
 def rank0_then_everyone(dist, rank, work, key="bench/rank0_done", timeout_s=900):
     """`work()` on rank 0 while the other ranks WAIT without spinning (blocked on the rendezvous store's socket, not in a
     collective: an RCCL barrier would burn a host core per waiting rank and disturb the CPU baseline being timed)."""
-    res = work() if rank == 0 else None
-    if dist is not None:
-        import datetime
+    if dist is None:
+        return work()
+    import datetime
 
-        from torch.distributed import distributed_c10d as c10d
+    from torch.distributed import distributed_c10d as c10d
 
-        store = c10d._get_default_store()
-        if rank == 0:
-            store.set(key, "1")
-        else:
-            store.wait([key], datetime.timedelta(seconds=timeout_s))
-        dist.barrier()      # everyone is here within milliseconds; the store's host may now go away
+    store = c10d._get_default_store()
+    res = None
+    if rank == 0:
+        try:
+            res = work()
+        finally:
+            store.set(key, "1")       # also when work() raised: the other ranks must not sit out the timeout
+    else:
+        store.wait([key], datetime.timedelta(seconds=timeout_s))
+    dist.barrier()      # everyone is here within milliseconds; the store's host may now go away
     return res
 
 

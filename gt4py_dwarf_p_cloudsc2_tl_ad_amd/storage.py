@@ -146,20 +146,27 @@ def plan_placement_grid(n: int, slab: int, free_bytes: Optional[int], *, spacing
     return grid, arena_need, spacings
 
 
-def tune_placement(*args, **kwargs):
-    """`_tune_placement` with the drivers' timing brackets switched off for its duration: an objective that runs a whole
-    harness (TaylorTest.run opens ~23 brackets per run) would otherwise pile up thousands of pending event pairs and have
-    `Timer._resolve()` - a device-wide synchronisation - land inside some candidate's timed window."""
-    from .framework import timing as _timing
+def _without_timing_brackets(fn):
+    """Run `fn` with the drivers' timing brackets switched off: an objective that runs a whole harness (TaylorTest.run opens
+    ~23 brackets per run) would otherwise pile up thousands of pending event pairs and have `Timer._resolve()` - a device-wide
+    synchronisation - land inside some candidate's timed window."""
+    import functools
 
-    was = _timing.set_enabled(False)
-    try:
-        return _tune_placement(*args, **kwargs)
-    finally:
-        _timing.set_enabled(was)
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        from .framework import timing as _timing
+
+        was = _timing.set_enabled(False)
+        try:
+            return fn(*args, **kwargs)
+        finally:
+            _timing.set_enabled(was)
+
+    return wrapper
 
 
-def _tune_placement(nx: int, nz: int, dtype: Any, device: Any, order, sources, launch, *, spacings=tuple(range(0, 64)),
+@_without_timing_brackets
+def tune_placement(nx: int, nz: int, dtype: Any, device: Any, order, sources, launch, *, spacings=tuple(range(0, 64)),
                    staggers=(FieldArena.STAGGER, 8448), shifts_mb=(0, 4096, 8192, 12288), wide_spacings=(),
                    wide_shifts_mb=tuple(range(0, 32769, 2048)), launches: int = 5, rounds: int = 3,
                    budget_s: float = 4.0, max_arena_bytes: int = 40 << 30, max_shift_spans: float = 4.0,

@@ -82,13 +82,23 @@ def main():
                 two_mb = (2 << 20) // item  # "arena2m:<stagger>:<lspad>:<extra>": slab spacing + <extra> x 2 MB
                 slab = ((nz + 1) * ls + 65536 // item + two_mb - 1) // two_mb * two_mb
                 slab += (int(parts[3]) if len(parts) > 3 else 0) * two_mb
+            jitter = None
+            if parts[0] == "arenaperm":     # "arenaperm:<seed>:<span>": 2-MB slabs as arena2m (stagger 2304), plus an IRREGULAR extra
+                two_mb = (2 << 20) // item  # offset of r_i x 2 MB per field, r_i random in [0, span): no arithmetic progression
+                seed, span = int(parts[1]), int(parts[2]) if len(parts) > 2 else 32
+                stagger = 2304
+                ls = nx
+                slab = ((nz + 1) * ls + 65536 // item + two_mb - 1) // two_mb * two_mb + span * two_mb
+                jitter = np.random.default_rng(seed).integers(0, span, size=80) * two_mb
             big = torch.zeros(80 * slab, dtype=storage.torch_dtype(np_dtype), device=dev)
             count = [0]
 
             def Z():
                 i = count[0]
                 count[0] += 1
-                o = i * slab + ((i * stagger) % 65536 // item if parts[0] == "arena2m" else 0)
+                o = i * slab + ((i * stagger) % 65536 // item if parts[0] in ("arena2m", "arenaperm") else 0)
+                if jitter is not None:
+                    o += int(jitter[i])
                 return storage.logical_view(big[o:o + (nz + 1) * ls].view(nz + 1, ls)[:, :nx])
         f = {}
         for k, v in s.items():

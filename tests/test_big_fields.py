@@ -14,7 +14,9 @@ WIDE = 4_194_304            # columns of the wide allocation: 138 x 4 194 304 x 
 
 
 @pytest.mark.gpu
-def test_nl_tl_ad_on_windows_of_a_4_6_GB_allocation(gpu):
+@pytest.mark.parametrize("switches", [{}, {"LEVAPLS2": True, "LREGCL": False}],
+                         ids=["driver-defaults", "evaporation-block-no-LREGCL"])
+def test_nl_tl_ad_on_windows_of_a_4_6_GB_allocation(gpu, switches):
     """NL, TL and AD through 1 000-column windows whose level stride is 4 194 304 fp64 elements: the launchers pick the
     `<big>` kernels, and their results are the BITS of the same columns in dense storages (same arithmetic on the same
     words; NL additionally against the oracle)."""
@@ -24,7 +26,7 @@ def test_nl_tl_ad_on_windows_of_a_4_6_GB_allocation(gpu):
     from gt4py_dwarf_p_cloudsc2_tl_ad_amd.stencils import compile_stencil
 
     nx = 1000                               # not a multiple of 64: the dense calls take the register-path kernels too
-    ext = externals(NLEV=NZ)
+    ext = externals(NLEV=NZ, **switches)    # the evaporation block adds accesses of its own (aph[nz], the parked cover of AD)
     fields, eta, dt = nl_case(nx, seed=71)
     fi = increments(fields, 0.01, ignore_supsat=True)
     eta_d = torch.as_tensor(eta, device=gpu)

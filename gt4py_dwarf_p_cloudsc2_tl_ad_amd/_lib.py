@@ -34,6 +34,7 @@ EXPORTED_SYMBOLS = (
     "cloudsc2_tl_f64", "cloudsc2_tl_f32",
     "cloudsc2_tl_incremented_f64", "cloudsc2_tl_incremented_f32",
     "cloudsc2_ad_f64", "cloudsc2_ad_f32",
+    "cloudsc2_ad_from_trajectory_f64", "cloudsc2_ad_from_trajectory_f32",
     "cloudsc2_saturation_f64", "cloudsc2_saturation_f32",
     "cloudsc2_state_increment_f64", "cloudsc2_state_increment_f32",
     "cloudsc2_perturbed_state_f64", "cloudsc2_perturbed_state_f32",
@@ -93,6 +94,9 @@ def _declare(lib: ctypes.CDLL) -> None:
             f = getattr(lib, f"cloudsc2_{name}_{sfx}")
             f.restype = c_int32
             f.argtypes = common + [parr, parr, c_void_p, parr, parr, c_double, c_void_p]
+        f = getattr(lib, f"cloudsc2_ad_from_trajectory_{sfx}")
+        f.restype = c_int32
+        f.argtypes = common + [parr, parr, c_void_p, c_void_p, c_void_p, parr, c_double, c_void_p]
         f = getattr(lib, f"cloudsc2_saturation_{sfx}")
         f.restype = c_int32
         f.argtypes = common + [c_void_p, c_void_p, c_void_p, c_void_p]

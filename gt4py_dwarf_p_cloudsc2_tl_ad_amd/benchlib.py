@@ -250,7 +250,9 @@ def harness_bench(args, rank, local_rank, world):
                 "norms' reductions (tangent_linear/validation.py:150-181)")
     else:
         seq_words = {"plain": sat_b + INC_WORDS_PER_COL + tl_b + tl_b,                                         # 19 095
-                     "fused": sat_b + (2193 + 2 * 1374) + tl_b}         # state_increment fused into cloudsc2_tl
+                     # fused: state_increment inside cloudsc2_tl (16 fields read, 20 written) + cloudsc2_ad from the TL call's
+                     # trajectory (16 inputs + 10 forcings + 2 fluxes read, 16 adjoints written = 44 words per level)
+                     "fused": sat_b + (2193 + 2 * 1374) + (2193 + 1374 + 2 * 138 + 16 * 137 + 2)}
         variants = [("graph", dict(graph=True), "plain"), ("fused", dict(fused=True), "fused"),
                     ("fused_graph", dict(fused=True, graph=True), "fused")]
         what = "saturation + state_increment + cloudsc2_tl + cloudsc2_ad (adjoint/validation.py:135-151, validation off)"

@@ -301,7 +301,7 @@ def check_resources(asm_nl, asm_tl, asm_ad) -> dict:
     for what, asm, key in (("nl_ring f64", asm_nl, "nl_ring_kernelIdLb0ELb1ELb1ELi3ELb0ELb0E"),
                            ("nl_ring f32", asm_nl, "nl_ring_kernelIfLb0ELb1ELb0ELi2ELb0ELb0E"),
                            ("tl f64", asm_tl, "9tl_kernelIdLb1ELb0ELb0ELb0E"), ("tl_ring f32", asm_tl, "tl_ring_kernelIfLb1ELb0E"),
-                           ("ad f64", asm_ad, "9ad_kernelIdLb1ELb0ELb0ELb0E"), ("ad f32", asm_ad, "9ad_kernelIfLb1ELb0ELb0ELb0E")):
+                           ("ad f64", asm_ad, "9ad_kernelIdLb1ELb0ELb0ELb0ELb0E"), ("ad f32", asm_ad, "9ad_kernelIfLb1ELb0ELb0ELb0ELb0E")):
         r = kernel_resources(asm, key)
         assert r["ScratchSize"] == 0, (what, "spills to scratch", r)
         out[what] = r
@@ -361,10 +361,12 @@ def check_all(out_dir=None) -> dict:
     # the batch detection is a heuristic (loads a few instructions apart, loops of >= 600 lines): it must have seen every
     # instantiation's level loop(s) - first of all the ones the drivers' defaults run (fp64, LREGCL, no evaporation)
     assert check_prefetch_distance(asm_tl, "9tl_kernelIdLb1ELb0ELb0ELb0E") == 1, "cloudsc2_tl fp64 default: level loop not seen"
-    assert check_prefetch_distance(asm_ad, "9ad_kernelIdLb1ELb0ELb0ELb0E") == 2, "cloudsc2_ad fp64 default: two sweeps not seen"
+    assert check_prefetch_distance(asm_ad, "9ad_kernelIdLb1ELb0ELb0ELb0ELb0E") == 2, "cloudsc2_ad fp64 default: two sweeps not seen"
     assert check_prefetch_distance(asm_nl, "9nl_kernelIdLb0ELb1ELb1ELi2ELb0E") == 1, "perturbed cloudsc2_nl fp64: loop not seen"
-    # (r04: + the BIG instantiations - 64-bit offsets - of the plain register-path kernels: tl 16 + 8, nl 28 + 8, ad 2 x 32)
-    assert pf["tl_kernel"] >= 24 and pf["nl_kernel"] >= 36 and pf["nl_taylor_multi_kernel"] >= 64 and pf["ad_kernel"] >= 64, pf
+    # (r04: + the BIG instantiations - 64-bit offsets - of the plain register-path kernels: tl 16 + 8, nl 28 + 8, ad 2 x 32;
+    #  + the 8 trajectory instantiations of ad_kernel, one sweep each)
+    assert pf["tl_kernel"] >= 24 and pf["nl_kernel"] >= 36 and pf["nl_taylor_multi_kernel"] >= 64 and pf["ad_kernel"] >= 72, pf
+    assert check_prefetch_distance(asm_ad, "9ad_kernelIdLb1ELb0ELb0ELb0ELb1E") == 1, "cloudsc2_ad_from_trajectory fp64: sweep not seen"
     res = check_resources(asm_nl, asm_tl, asm_ad)
     n_asm = sum(check_inline_asm_vmem(a, f) for a, f in ((asm_nl, "cloudsc2_nl.hip"), (asm_tl, "cloudsc2_tl.hip"),
                                                          (asm_ad, "cloudsc2_ad.hip")))

@@ -949,6 +949,8 @@ struct ADArgs {
     MPtrs<T, NL_NUM_IN> oadj;
     T dt;
     int keep_from;
+    const T* traj_l;   // TRAJ instantiation only: the rain / snow fluxes ENTERING each level (= out_fplsl / out_fplsn of a
+    const T* traj_n;   // cloudsc2_nl / cloudsc2_tl call on the same state), read instead of recomputed by sweep 1
 };
 #ifndef CS2_AD_KARG
 #define CS2_AD_KARG 1   // 1: field pointers are re-read from the kernarg segment (scalar loads) on every level
@@ -962,12 +964,19 @@ struct ADFields : KernArgs<ADArgs<T>> {
     __device__ __forceinline__ const T* outc(int i) const { return this->ka->out.p[i]; }
     __device__ __forceinline__ T* oadj(int i) const { return this->ka->oadj.p[i]; }
     __device__ __forceinline__ const T* oadjc(int i) const { return this->ka->oadj.p[i]; }
+    __device__ __forceinline__ const T* traj_l() const { return this->ka->traj_l; }
+    __device__ __forceinline__ const T* traj_n() const { return this->ka->traj_n; }
 };
 
 // fp32 without the evaporation block: three waves per SIMD (<= 168 VGPRs) is what the LDS parking was built for (+4.7 %,
 // DESIGN 3.5); r03's two extra raw forcing words took the unconstrained allocation to 170 VGPRs = two waves, so it is asked for.
 // BIG: 64-bit byte offsets (fields of 4 GiB and more, see offset_t in cloudsc2_common.hpp).
-template <typename T, bool REG, bool FIX, bool EVAP, bool BIG = false>
+// TRAJ (BUILD EXTENSION, C ABI cloudsc2_ad_from_trajectory_*): the symmetry test calls cloudsc2_tl and then cloudsc2_ad on
+// the same state (adjoint/validation.py:135-151), and the only loop-carried trajectory values sweep 2 needs from sweep 1
+// are the two precipitation fluxes entering each level - which the TL call has just written as out_fplsl / out_fplsn.
+// With TRAJ the kernel skips sweep 1 (no NL outputs are written) and reads those two fields from `traj_l` / `traj_n`:
+// 44 words per level and column instead of 70.  Without the evaporation block only (its parked cover has no such source).
+template <typename T, bool REG, bool FIX, bool EVAP, bool BIG = false, bool TRAJ = false>
 __global__ void __launch_bounds__(kColBlock, (sizeof(T) == 4 && !EVAP) ? 3 : 1)
 ad_kernel(const ADArgs<T> A) {
     Ext<T> e = A.e;
@@ -1012,14 +1021,15 @@ ad_kernel(const ADArgs<T> A) {
     const T trpaus = trpaus_prescan<T, false, O>(F.in(NL_IN_T), F.in(NL_IN_TND_CML_T), lsb, colb, dt, s_eta, klo, khi);
     const CrhCol<T> crh = crh_setup<T>(trpaus);
 
+    static_assert(!(TRAJ && EVAP), "the trajectory variant has no source for the evaporation block's parked cover");
     // ---------------- sweep 1: trajectory + NL outputs (:146-475)
-    stg(F.out(NL_OUT_FPLSL), colb, T(0.0));
-    stg(F.out(NL_OUT_FPLSN), colb, T(0.0));
-    stg(F.out(NL_OUT_FHPSL), colb, T(0.0));
-    stg(F.out(NL_OUT_FHPSN), colb, T(0.0));
     const T aph_s = EVAP ? ldg(F.in(NL_IN_APH), O(nz) * lsb + colb) : T(1.0);
-    #define park F.oadj(NL_IN_MFD)  // EVAP: level k holds the cover entering level k until sweep 2 overwrites it
-    {
+#define park F.oadj(NL_IN_MFD)  // EVAP: level k holds the cover entering level k until sweep 2 overwrites it
+    if constexpr (!TRAJ) {
+        stg(F.out(NL_OUT_FPLSL), colb, T(0.0));
+        stg(F.out(NL_OUT_FPLSN), colb, T(0.0));
+        stg(F.out(NL_OUT_FHPSL), colb, T(0.0));
+        stg(F.out(NL_OUT_FHPSN), colb, T(0.0));
         T rfl = T(0.0), sfl = T(0.0), covptot = T(0.0);
         T aph_k = ldg(F.in(NL_IN_APH), colb);
         O o = colb;
@@ -1052,7 +1062,7 @@ ad_kernel(const ADArgs<T> A) {
             xa = xn;
             o += lsb;
         }
-    }
+    }   // !TRAJ
 
     // ---------------- sweep 2: adjoint (:479-996), k = nz-1 .. 0
     ADBack<T> b;
@@ -1065,8 +1075,8 @@ ad_kernel(const ADArgs<T> A) {
         ADIn<T> xa = ad_load<T>(F, lsb, o, k >= keep_from);
         ADForce<T> fa = ad_load_force<T, EVAP>(F, e, lsb, o);
         T aph_k = ldg_sel(F.in(NL_IN_APH), o, k >= keep_from);
-        T sfl = ldg_sel(F.outc(NL_OUT_FPLSN), o, k >= keep_from);
-        T rfl = ldg_sel(F.outc(NL_OUT_FPLSL), o, k >= keep_from);
+        T sfl = ldg_sel(TRAJ ? F.traj_n() : F.outc(NL_OUT_FPLSN), o, k >= keep_from);
+        T rfl = ldg_sel(TRAJ ? F.traj_l() : F.outc(NL_OUT_FPLSL), o, k >= keep_from);
         T cov = EVAP ? ldg(F.oadjc(NL_IN_MFD), o) : T(0.0);
         for (; k >= 0; --k) {
             F.fresh();
@@ -1080,8 +1090,8 @@ ad_kernel(const ADArgs<T> A) {
                 xn.aph1 = aph_k;   // aph[k]: already here as this level's upper half level (the load above is dropped)
                 fn = ad_load_force<T, EVAP>(F, e, lsb, om);
                 aph_n = ldg_sel(F.in(NL_IN_APH), om, keep_m);
-                sfl_n = ldg_sel(F.outc(NL_OUT_FPLSN), om, keep_m);
-                rfl_n = ldg_sel(F.outc(NL_OUT_FPLSL), om, keep_m);
+                sfl_n = ldg_sel(TRAJ ? F.traj_n() : F.outc(NL_OUT_FPLSN), om, keep_m);
+                rfl_n = ldg_sel(TRAJ ? F.traj_l() : F.outc(NL_OUT_FPLSL), om, keep_m);
                 if constexpr (EVAP) cov_n = ldg(F.oadjc(NL_IN_MFD), om);
             }
             ADTraj<T> r;
@@ -1124,9 +1134,12 @@ ad_kernel(const ADArgs<T> A) {
 #undef park
 }
 
+// traj_l / traj_n != nullptr: the trajectory variant (TRAJ above); `out` may then be nullptr (nothing of it is touched).
 template <typename T>
 int launch_ad(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* const* in, const T* const* in_adj,
-              const T* eta, T* const* out, T* const* out_adj, double dt, hipStream_t stream) {
+              const T* eta, T* const* out, T* const* out_adj, double dt, hipStream_t stream, const T* traj_l,
+              const T* traj_n) {
+    const bool traj = traj_l != nullptr && traj_n != nullptr;
     const bool evap = p.LEVAPLS2 || p.LDRAIN1D;
     const Ext<T> e = make_ext<T>(p);
     CPtrs<T, NL_NUM_IN> ci;
@@ -1134,7 +1147,7 @@ int launch_ad(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
     MPtrs<T, NL_NUM_OUT> co;
     MPtrs<T, NL_NUM_IN> coa;
     for (int i = 0; i < NL_NUM_IN; ++i) { ci.p[i] = in[i]; coa.p[i] = out_adj[i]; }
-    for (int i = 0; i < NL_NUM_OUT; ++i) { ca.p[i] = in_adj[i]; co.p[i] = out[i]; }
+    for (int i = 0; i < NL_NUM_OUT; ++i) { ca.p[i] = in_adj[i]; co.p[i] = out ? out[i] : nullptr; }
     const dim3 grid((nx + kColBlock - 1) / kColBlock), block(kColBlock);
     const size_t smem = 2 * size_t(nz + 1) * sizeof(T) + (kADPark<T> ? size_t(CS2_AD_PARK_COUNT) * kColBlock * sizeof(T) : 0);
     const T tdt = static_cast<T>(dt);
@@ -1154,7 +1167,8 @@ int launch_ad(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
         const int levels = int((uint64_t(CS2_AD_KEEP_MB) << 20) / (per_level ? per_level : 1));
         keep_from = levels >= nz ? 0 : nz - levels;
     }
-    const ADArgs<T> args = {e, kc, xk, nx, nz, ls, ci, ca, eta, co, coa, tdt, keep_from};
+    if (traj && (evap || big)) return -2;   // the trajectory variant: driver switches, 32-bit offsets
+    const ADArgs<T> args = {e, kc, xk, nx, nz, ls, ci, ca, eta, co, coa, tdt, keep_from, traj_l, traj_n};
 #define CS2_AD_LAUNCH(R, F, E)                                                                                         \
     do {                                                                                                               \
         if (big) CS2_AD_LAUNCH_B(R, F, E, true); else CS2_AD_LAUNCH_B(R, F, E, false);                                 \
@@ -1168,24 +1182,36 @@ int launch_ad(const Cloudsc2Params& p, int nx, int nz, int64_t ls, const T* cons
         }                                                                                                              \
         hipLaunchKernelGGL(kern, grid, block, smem, stream, args);         \
     } while (0)
+#define CS2_AD_LAUNCH_T(R, F)                                                                                          \
+    do {                                                                                                               \
+        auto kern = ad_kernel<T, R, F, false, false, true>;                                                            \
+        if (smem > size_t(64) * 1024) {                                                                                \
+            static std::atomic<size_t> attr_set[kMaxDevices] = {};                                                     \
+            if (!lds_opt_in(kern, attr_set, dev, smem)) return -1;                                                     \
+        }                                                                                                              \
+        hipLaunchKernelGGL(kern, grid, block, smem, stream, args);                                                     \
+    } while (0)
 #define CS2_AD_LAUNCH_E(R, F) \
     do {                      \
-        if (evap) CS2_AD_LAUNCH(R, F, true); else CS2_AD_LAUNCH(R, F, false); \
+        if (traj) CS2_AD_LAUNCH_T(R, F); \
+        else if (evap) CS2_AD_LAUNCH(R, F, true); else CS2_AD_LAUNCH(R, F, false); \
     } while (0)
     if (reg && !fix) CS2_AD_LAUNCH_E(true, false);
     else if (!reg && !fix) CS2_AD_LAUNCH_E(false, false);
     else if (reg && fix) CS2_AD_LAUNCH_E(true, true);
     else CS2_AD_LAUNCH_E(false, true);
 #undef CS2_AD_LAUNCH_E
+#undef CS2_AD_LAUNCH_T
 #undef CS2_AD_LAUNCH
 #undef CS2_AD_LAUNCH_B
-    note_kernel(big ? "cs2::ad_kernel<big>" : "cs2::ad_kernel");
+    note_kernel(traj ? "cs2::ad_kernel<trajectory>" : big ? "cs2::ad_kernel<big>" : "cs2::ad_kernel");
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 template int launch_ad<double>(const Cloudsc2Params&, int, int, int64_t, const double* const*, const double* const*,
-                               const double*, double* const*, double* const*, double, hipStream_t);
+                               const double*, double* const*, double* const*, double, hipStream_t, const double*,
+                               const double*);
 template int launch_ad<float>(const Cloudsc2Params&, int, int, int64_t, const float* const*, const float* const*,
-                              const float*, float* const*, float* const*, double, hipStream_t);
+                              const float*, float* const*, float* const*, double, hipStream_t, const float*, const float*);
 
 }  // namespace cs2

@@ -24,7 +24,7 @@ int launch_tl(const Cloudsc2Params&, int, int, int64_t, const T* const*, const T
               T* const*, double, hipStream_t, double);
 template <typename T>
 int launch_ad(const Cloudsc2Params&, int, int, int64_t, const T* const*, const T* const*, const T*, T* const*,
-              T* const*, double, hipStream_t);
+              T* const*, double, hipStream_t, const T* traj_l = nullptr, const T* traj_n = nullptr);
 template <typename T>
 int launch_saturation(const Cloudsc2Params&, int, int, int64_t, const T*, const T*, T*, hipStream_t);
 template <typename T>
@@ -216,6 +216,26 @@ int ad_impl(const char* fn, const Cloudsc2Params* p, int32_t nx, int32_t nz, int
 }
 
 template <typename T>
+int ad_traj_impl(const char* fn, const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls, const T* const* in,
+                 const T* const* in_adj, const T* eta, const T* traj_fplsl, const T* traj_fplsn, T* const* out_adj, double dt,
+                 void* stream) {
+    if (int rc = check_common(fn, p, nx, nz, ls)) return rc;
+    if (nx == 0) return CLOUDSC2_OK;
+    if (int rc = check_ptrs(fn, "in", in, NL_NUM_IN)) return rc;
+    if (int rc = check_ptrs(fn, "in_adj", in_adj, NL_NUM_OUT)) return rc;
+    if (int rc = check_ptrs(fn, "out_adj", const_cast<const T* const*>(out_adj), NL_NUM_IN)) return rc;
+    if (!eta || !traj_fplsl || !traj_fplsn) return fail(CLOUDSC2_E_ARG, "%s: eta / traj_fplsl / traj_fplsn is NULL", fn);
+    if (p->ICALL != 0) return fail(CLOUDSC2_E_UNSUPPORTED, "%s: ICALL=%d unsupported", fn, p->ICALL);
+    if (p->LEVAPLS2 || p->LDRAIN1D)
+        return fail(CLOUDSC2_E_UNSUPPORTED, "%s: the trajectory variant covers the driver switches only (no evaporation "
+                    "block: its parked precipitation cover has no counterpart among the NL outputs) - use cloudsc2_ad", fn);
+    if (!(dt > 0.0)) return fail(CLOUDSC2_E_ARG, "%s: dt=%g must be > 0", fn, dt);
+    if (p->NLEV != nz) return fail(CLOUDSC2_E_ARG, "%s: NLEV=%d != nz=%d", fn, p->NLEV, nz);
+    return launched(fn, cs2::launch_ad<T>(*p, nx, nz, ls, in, in_adj, eta, nullptr, out_adj, dt,
+                                          static_cast<hipStream_t>(stream), traj_fplsl, traj_fplsn));
+}
+
+template <typename T>
 int sat_impl(const char* fn, const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls, const T* ap, const T* t,
              T* qsat, void* stream) {
     if (int rc = check_common(fn, p, nx, nz, ls)) return rc;
@@ -354,6 +374,18 @@ int32_t cloudsc2_ad_f32(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t
                         const float* const* in_adj, const float* eta, float* const* out, float* const* out_adj,
                         double dt, void* stream) {
     return ad_impl<float>("cloudsc2_ad_f32", p, nx, nz, ls, in, in_adj, eta, out, out_adj, dt, stream);
+}
+int32_t cloudsc2_ad_from_trajectory_f64(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls, const double* const* in,
+                                        const double* const* in_adj, const double* eta, const double* traj_fplsl,
+                                        const double* traj_fplsn, double* const* out_adj, double dt, void* stream) {
+    return ad_traj_impl<double>("cloudsc2_ad_from_trajectory_f64", p, nx, nz, ls, in, in_adj, eta, traj_fplsl, traj_fplsn,
+                                out_adj, dt, stream);
+}
+int32_t cloudsc2_ad_from_trajectory_f32(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls, const float* const* in,
+                                        const float* const* in_adj, const float* eta, const float* traj_fplsl,
+                                        const float* traj_fplsn, float* const* out_adj, double dt, void* stream) {
+    return ad_traj_impl<float>("cloudsc2_ad_from_trajectory_f32", p, nx, nz, ls, in, in_adj, eta, traj_fplsl, traj_fplsn,
+                               out_adj, dt, stream);
 }
 int32_t cloudsc2_saturation_f64(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t ls, const double* ap,
                                 const double* t, double* qsat, void* stream) {

@@ -46,7 +46,8 @@ def core(args):
     if io.output_csv_file is not None:          # run_symmetry_test.py:106-121 (+ the build's GB/s and roofline columns)
         from ..framework.output import write_performance_to_csv
 
-        seq = (["saturation", "cloudsc2_tl_incremented", "cloudsc2_ad"] if st.fused
+        seq = (["saturation", "cloudsc2_tl_incremented",
+                "cloudsc2_ad_from_trajectory" if st.cloudsc2_ad_from_trajectory is not None else "cloudsc2_ad"] if st.fused
                else ["saturation", "state_increment", "cloudsc2_tl", "cloudsc2_ad"])
         write_performance_to_csv(io.output_csv_file, io.host_name, cfg.precision, "ad-" + cfg.gt4py_config.backend,
                                  ctx["nx"], cfg.num_threads, 1, cfg.num_runs, mean, std, 0, 0, stencils=seq)
@@ -66,7 +67,8 @@ def main(argv=None):
     ap.add_argument("--ad-traj-fix", action="store_true",
                     help="use the AD kernel whose freezing tests match NL/TL (build extension, docs/DESIGN_r03_detail.md 3.3)")
     ap.add_argument("--fused", action="store_true",
-                    help="timed call: state_increment fused into cloudsc2_tl (build extension cloudsc2_tl_incremented)")
+                    help="timed call: state_increment fused into cloudsc2_tl (build extension cloudsc2_tl_incremented) and "
+                         "cloudsc2_ad without its forward sweep, fed with the TL call's fluxes (cloudsc2_ad_from_trajectory)")
     ap.add_argument("--graph", action="store_true",
                     help="capture the timed call (saturation, state_increment, cloudsc2_tl, cloudsc2_ad) in a HIP graph and "
                          "replay it (one host call per run)")

@@ -15,7 +15,9 @@ WORDS_PER_COLUMN = {"saturation": 411, "state_increment": 4416, "perturbed_state
                     # per CALL with the Taylor test's ten step sizes = two launches of five, increments formed in the kernel:
                     # each launch reads the 16 state + 10 reference fields once
                     "cloudsc2_nl_taylor_multi": 2 * 3567,
-                    "cloudsc2_tl": 7134, "cloudsc2_tl_incremented": 4941, "cloudsc2_ad": 7134}
+                    "cloudsc2_tl": 7134, "cloudsc2_tl_incremented": 4941, "cloudsc2_ad": 7134,
+                    # 16 inputs + 10 forcings + 2 fluxes read, 16 adjoints written
+                    "cloudsc2_ad_from_trajectory": 2193 + 1374 + 2 * 138 + 2194}
 HBM_PEAK_GBS = 8000.0   # MI355X spec peak the roofline columns are quoted against
 _WORD = {"double": 8, "single": 4}
 

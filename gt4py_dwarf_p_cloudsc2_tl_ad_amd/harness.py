@@ -20,7 +20,9 @@ observable contract).  Differences, all on the measurement side:
     and `state_increment` is fused into cloudsc2_tl and into that kernel (stencil `cloudsc2_tl_incremented`, `f_inc=`):
     the increments f1 * state are formed in the kernels and never stored (`state_i` stays empty in this mode);
   * `SymmetryTest(..., fused=True)`: the TIMED call (validation off) runs `cloudsc2_tl_incremented` instead of
-    state_increment + cloudsc2_tl; the validated call keeps the separate launches (its norm needs `state_i`);
+    state_increment + cloudsc2_tl, and (r04) `cloudsc2_ad_from_trajectory` instead of cloudsc2_ad - the adjoint sweep alone,
+    fed with the TL call's flux outputs instead of recomputing the NL trajectory; the validated call keeps the separate,
+    complete launches (its norms need `state_i`, and it comes first, so the AD output storages exist);
   * `graph=True` (both harnesses) captures the run's kernel sequence once into a HIP graph and replays it: one host
     call per run instead of the Python + ctypes path of ~35 launches (the caller must pass the same state storages);
   * `SymmetryTest(..., ad_traj_fix=True)` selects the AD kernel variant whose freezing tests match
@@ -37,8 +39,8 @@ import torch
 
 from .framework.timing import timing
 from .reductions import column_dots, field_sums
-from .physics import (Cloudsc2AD, Cloudsc2NL, Cloudsc2NLPerturbed, Cloudsc2TL, Cloudsc2TLIncremented, PerturbedState,
-                      Saturation, StateIncrement)
+from .physics import (Cloudsc2AD, Cloudsc2ADFromTrajectory, Cloudsc2NL, Cloudsc2NLPerturbed, Cloudsc2TL,
+                      Cloudsc2TLIncremented, PerturbedState, Saturation, StateIncrement)
 
 _TENDS = ("f_t", "f_q", "f_ql", "f_qi")
 _DIAGS = ("f_clc", "f_fhpsl", "f_fhpsn", "f_fplsl", "f_fplsn", "f_covptot")
@@ -312,10 +314,15 @@ class SymmetryTest:
                                       ad_traj_fix=ad_traj_fix, **kw)
         self.state_increment = StateIncrement(computational_grid, factor, ignore_supsat=True, **kw)
         self.cloudsc2_tl_incremented = None
+        self.cloudsc2_ad_from_trajectory = None
         if fused:
             self.cloudsc2_tl_incremented = Cloudsc2TLIncremented(
                 computational_grid, factor, True, lphylin, ldrain1d, yoethf_params, yomcst_params, yrecldp_params,
                 yrephli_params, yrncl_params, yrphnc_params, **kw)
+            if not ldrain1d:        # (the trajectory variant covers the driver switches: no evaporation block)
+                self.cloudsc2_ad_from_trajectory = Cloudsc2ADFromTrajectory(
+                    computational_grid, lphylin, ldrain1d, yoethf_params, yomcst_params, yrecldp_params, yrephli_params,
+                    yrncl_params, yrphnc_params, ad_traj_fix=ad_traj_fix, **kw)
         self.diags_sat: Dict[str, Any] = {}
         self.state_i: Dict[str, Any] = {}
         self.tends_tl: Dict[str, Any] = {}
@@ -373,8 +380,12 @@ class SymmetryTest:
             state["f_tnd_" + n[2:]] = self.tends_tl[n]
             state["f_tnd_" + n[2:] + "_i"] = self.tends_tl[n + "_i"]
         state.update(self.diags_tl)
-        self.tends_ad, self.diags_ad = self.cloudsc2_ad(state, timestep, out_tendencies=self.tends_ad,
-                                                        out_diagnostics=self.diags_ad)
+        # timed call of the fused mode: cloudsc2_ad without its forward sweep - the two fluxes it would recompute are the
+        # TL call's f_fplsl / f_fplsn, in the state since the line above (the NL outputs of tends_ad / diags_ad are then
+        # not written: they are the TL call's)
+        ad = (self.cloudsc2_ad_from_trajectory if self.fused and not enable_validation and self.tends_ad
+              and self.cloudsc2_ad_from_trajectory is not None else self.cloudsc2_ad)
+        self.tends_ad, self.diags_ad = ad(state, timestep, out_tendencies=self.tends_ad, out_diagnostics=self.diags_ad)
         return norm1
 
     def _norm1(self) -> torch.Tensor:

@@ -354,8 +354,9 @@ class Cloudsc2AD(ImplicitTendencyComponent):
         ext = _externals(yoethf_params, yomcst_params, yrecldp_params, yrephli_params, yrncl_params, yrphnc_params,
                          ICALL=0, LPHYLIN=lphylin, LDRAIN1D=ldrain1d, NLEV=computational_grid.nz,
                          ZEPS1=1e-12, ZEPS2=1e-10, ZQMAX=0.5, ZSCAL=0.9, AD_TRAJ_FIX=int(ad_traj_fix))
-        self.cloudsc2 = self.compile_stencil("cloudsc2_ad", ext)
+        self.cloudsc2 = self.compile_stencil(self._stencil_name, ext)
 
+    _stencil_name = "cloudsc2_ad"
     _ADJ_STATE = ("ap", "aph", "lu", "lude", "mfd", "mfu", "q", "qi", "ql", "qsat", "supsat", "t")
 
     @cached_property
@@ -389,3 +390,30 @@ class Cloudsc2AD(ImplicitTendencyComponent):
             kw["out_tnd_cml_" + n + "_i"] = out_tendencies["f_cml_" + n + "_i"]
         self.cloudsc2(**kw, in_eta=state["f_eta"], dt=self.gt4py_config.dtypes.float(timestep.total_seconds()),
                       domain=(g.nx, 1, g.nz + 1), **_stencil_common(self))
+
+
+class Cloudsc2ADFromTrajectory(Cloudsc2AD):
+    """BUILD EXTENSION: `Cloudsc2AD` called right after `Cloudsc2TL` on the same state - the symmetry test's sequence
+    (adjoint/validation.py:135-151) - without the forward sweep that recomputes the NL trajectory (stencil
+    `cloudsc2_ad_from_trajectory`).  The state must carry the TL call's NL flux outputs `f_fplsl` / `f_fplsn` (the harness
+    puts the TL diagnostics into the state anyway, :149-150).  Only the adjoint fields are written; the NL tendencies /
+    diagnostics of the output dicts are NOT (they are the TL call's).  Driver switches only."""
+
+    _stencil_name = "cloudsc2_ad_from_trajectory"
+
+    @cached_property
+    def input_grid_properties(self):
+        props = dict(super().input_grid_properties)
+        props.update({"f_fplsl": _prop("fplsl"), "f_fplsn": _prop("fplsn")})
+        return props
+
+    def array_call(self, state, timestep: timedelta, out_tendencies, out_diagnostics, overwrite_tendencies) -> None:
+        g = self.computational_grid
+        kw = {"in_" + n: state["f_" + n] for n in NL_IN}
+        kw.update({"in_" + n + "_i": state["f_" + n + "_i"] for n in NL_OUT})
+        kw.update({"out_" + n + "_i": out_diagnostics["f_" + n + "_i"] for n in self._ADJ_STATE})
+        for n in ("q", "qi", "ql", "t"):
+            kw["out_tnd_cml_" + n + "_i"] = out_tendencies["f_cml_" + n + "_i"]
+        self.cloudsc2(**kw, traj_fplsl=state["f_fplsl"], traj_fplsn=state["f_fplsn"], in_eta=state["f_eta"],
+                      dt=self.gt4py_config.dtypes.float(timestep.total_seconds()), domain=(g.nx, 1, g.nz + 1),
+                      **_stencil_common(self))

@@ -414,6 +414,29 @@ class Cloudsc2ADStencil(HipStencil):
             scalar, stream)
 
 
+class Cloudsc2ADFromTrajectoryStencil(HipStencil):
+    """BUILD EXTENSION `cloudsc2_ad_from_trajectory`: `cloudsc2_ad` without its forward sweep (C ABI
+    `cloudsc2_ad_from_trajectory_*`).  Fields of `cloudsc2_ad` minus the ten `out_*` NL outputs, plus `traj_fplsl` /
+    `traj_fplsn`: the flux outputs of a cloudsc2_nl / cloudsc2_tl call on the same state (read-only).  Only the 16
+    `out_*_i` adjoints are written.  Driver switches only (no evaporation block)."""
+
+    name = "cloudsc2_ad_from_trajectory"
+
+    def _field_names(self):
+        return (tuple("in_" + n for n in NL_IN) + tuple("in_" + n + "_i" for n in NL_OUT) + ("traj_fplsl", "traj_fplsn")
+                + tuple("out_" + n + "_i" for n in NL_IN))
+
+    def _launch(self, fields, eta, scalar, nx, nz, ls, sfx, stream):
+        if eta is None:
+            raise TypeError(f"{self.name}: missing field argument 'in_eta'")
+        self._set_nlev(nz)
+        return self._fn("ad_from_trajectory", sfx)(
+            ctypes.byref(self.params), nx, nz, ls,
+            _ptrs(fields, ["in_" + n for n in NL_IN]), _ptrs(fields, ["in_" + n + "_i" for n in NL_OUT]),
+            eta.data_ptr(), fields["traj_fplsl"].data_ptr(), fields["traj_fplsn"].data_ptr(),
+            _ptrs(fields, ["out_" + n + "_i" for n in NL_IN]), scalar, stream)
+
+
 class SaturationStencil(HipStencil):
     """`saturation` - common/_stencils/saturation.py:23-42; domain (nx, 1, nz)."""
 
@@ -473,6 +496,7 @@ STENCILS: Dict[str, type] = {
     "cloudsc2_tl": Cloudsc2TLStencil,
     "cloudsc2_tl_incremented": Cloudsc2TLIncrementedStencil,    # build extension (state_increment fused in)
     "cloudsc2_ad": Cloudsc2ADStencil,
+    "cloudsc2_ad_from_trajectory": Cloudsc2ADFromTrajectoryStencil,   # build extension (no forward sweep)
     "saturation": SaturationStencil,
     "state_increment": StateIncrementStencil,
     "perturbed_state": PerturbedStateStencil,

@@ -228,6 +228,24 @@ int32_t cloudsc2_ad_f32(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t
                         const float* const* in, const float* const* in_adj, const float* eta,
                         float* const* out, float* const* out_adj, double dt, void* stream);
 
+/* ---- cloudsc2_ad WITHOUT its forward sweep (BUILD EXTENSION).  The symmetry test calls cloudsc2_tl and then cloudsc2_ad on
+ * the same state (adjoint/validation.py:135-151).  The kernel behind cloudsc2_ad_* recomputes the NL trajectory in a first
+ * sweep only to obtain, per level, the rain / snow fluxes entering it - and those are the NL outputs out_fplsl / out_fplsn
+ * the TL call has just written.  Here they are READ (`traj_fplsl`, `traj_fplsn`: (nz+1)-level fields as cloudsc2_nl /
+ * cloudsc2_tl write them) and the forward sweep is skipped: 44 words per level and column instead of 70.  Nothing but
+ * `out_adj` is written (the recomputed NL outputs of cloudsc2_ad_* are not produced: they are the TL call's).  With fluxes
+ * that come from cloudsc2_ad_*'s own `out` the adjoints are bit-identical to that call's; with a TL call's they agree to
+ * rounding (the two kernels contract the same formulas differently).  Driver switches only: LEVAPLS2 / LDRAIN1D are
+ * refused (CLOUDSC2_E_UNSUPPORTED), as are fields of 4 GiB and more. */
+int32_t cloudsc2_ad_from_trajectory_f64(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t lev_stride,
+                                        const double* const* in, const double* const* in_adj, const double* eta,
+                                        const double* traj_fplsl, const double* traj_fplsn, double* const* out_adj, double dt,
+                                        void* stream);
+int32_t cloudsc2_ad_from_trajectory_f32(const Cloudsc2Params* p, int32_t nx, int32_t nz, int64_t lev_stride,
+                                        const float* const* in, const float* const* in_adj, const float* eta,
+                                        const float* traj_fplsl, const float* traj_fplsn, float* const* out_adj, double dt,
+                                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

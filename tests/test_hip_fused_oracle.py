@@ -287,3 +287,62 @@ def test_symmetry_driver_graph_mode(gpu, capsys):
                     else:                        # graph replay of the same launches: bit for bit
                         assert torch.equal(da[k].data, db[k].data), (extra, dct, k)
     assert "HOORAY" in capsys.readouterr().out
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("flags", [dict(), dict(LREGCL=False, AD_TRAJ_FIX=1)])
+def test_ad_from_trajectory_equals_cloudsc2_ad_and_the_oracle(gpu, flags, dtype):
+    """BUILD EXTENSION `cloudsc2_ad_from_trajectory` (r04): cloudsc2_ad without its forward sweep, fed with the flux outputs of
+    a call on the same state.  (a) With the fluxes cloudsc2_ad itself wrote, the 16 adjoint fields are the BITS of
+    cloudsc2_ad's; (b) with the fluxes of the cloudsc2_tl call that precedes it in the symmetry test
+    (adjoint/validation.py:135-151) they agree to rounding and match the oracle's cloudsc2_ad like cloudsc2_ad does; (c) the
+    forcings and the trajectory fields are left untouched, nothing but the adjoints is written; (d) the evaporation block is
+    refused by name."""
+    import torch
+
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd import _lib, storage
+    from gt4py_dwarf_p_cloudsc2_tl_ad_amd.stencils import compile_stencil
+    from helpers import NL_IN, from_device, increments, run_oracle_ad, run_oracle_tl
+    from test_hip_tl_ad import run_hip_ad, run_hip_tl
+
+    lev = lambda n: nz + 1 if n in ("aph", "lu") else nz  # noqa: E731  (out_aph_i / out_lu_i are written on all nz+1 levels)
+    nx, nz = 333, 137
+    ext = externals(NLEV=nz, **flags)
+    fields, eta, dt = nl_case(nx, dtype=dtype, seed=83)
+    fi = increments(fields, 0.01, ignore_supsat=True)
+    _, tl_i = run_oracle_tl(fields, fi, eta, dt, ext)
+    forcing = {n: tl_i[n] for n in NL_OUT}                       # the symmetry test's forcing: the TL perturbation outputs
+    want_nl, want_adj = run_oracle_ad(fields, forcing, eta, dt, ext)
+    ad_nl, ad_adj = run_hip_ad(fields, forcing, eta, dt, ext, gpu, nx, nz)
+    tl_nl, _ = run_hip_tl(fields, fi, eta, dt, ext, gpu, nx, nz)
+
+    dev = to_device(fields, gpu)
+    frc = to_device({"in_" + n + "_i": forcing[n] for n in NL_OUT}, gpu)
+    st = compile_stencil("cloudsc2_ad_from_trajectory", ext)
+    com = dict(in_eta=torch.as_tensor(eta, device=gpu), dt=dtype(dt), origin=(0, 0, 0), domain=(nx, 1, nz + 1),
+               validate_args=True, exec_info=None)
+
+    def run(traj):
+        tr = to_device({"traj_fplsl": traj["fplsl"], "traj_fplsn": traj["fplsn"]}, gpu)
+        before = {k: v.clone() for k, v in {**frc, **tr}.items()}
+        outs = {"out_" + n + "_i": storage.from_klayout(np.full((nz + 1, nx), np.nan, dtype=dtype), dtype, gpu) for n in NL_IN}
+        st(**dev, **frc, **tr, **outs, **com)
+        torch.cuda.synchronize()
+        assert _lib.last_kernel() == "cs2::ad_kernel<trajectory>"
+        for k, v in before.items():
+            assert torch.equal({**frc, **tr}[k], v), k                                        # (c) read-only
+        return {n: from_device(outs["out_" + n + "_i"]) for n in NL_IN}
+
+    own = run(ad_nl)                                              # (a) cloudsc2_ad's own recomputed fluxes
+    for n in NL_IN:
+        assert np.array_equal(own[n][:lev(n)], ad_adj[n][:lev(n)], equal_nan=True), n
+    from_tl = run(tl_nl)                                          # (b) the TL call's fluxes
+    rt = 1e3 if dtype == np.float64 else 1e2
+    for n in NL_IN:
+        k = lev(n)
+        assert_close(f"ad_from_trajectory(TL fluxes) vs cloudsc2_ad out_{n}_i", from_tl[n][:k], ad_adj[n][:k], dtype, rtol_mul=rt)
+        assert_close(f"ad_from_trajectory vs oracle out_{n}_i", from_tl[n][:k], want_adj[n][:k], dtype, rtol_mul=rt)
+    with pytest.raises(ValueError, match="no evaporation"):      # (d)
+        compile_stencil("cloudsc2_ad_from_trajectory", externals(NLEV=nz, LEVAPLS2=True))(
+            **dev, **frc, **to_device({"traj_fplsl": ad_nl["fplsl"], "traj_fplsn": ad_nl["fplsn"]}, gpu),
+            **{"out_" + n + "_i": storage.zeros(nx, nz, dtype, gpu) for n in NL_IN}, **com)

@@ -67,8 +67,8 @@ def test_register_path_prefetch_is_not_waited_for_at_the_load_site(tl_asm, nl_as
     assert isa.check_prefetch_distance(tl_asm, "9tl_kernelI") == 24              # T x REG x EVAP x {INC, plain, plain BIG}
     assert isa.check_prefetch_distance(nl_asm, "9nl_kernelI", skip=r"Lb1ELb[01]ELb[01]ELi3E") == 36       # + 8 BIG (FUSE = 0)
     assert isa.check_prefetch_distance(nl_asm, "nl_taylor_multi_kernelI") >= 64
-    assert isa.check_prefetch_distance(ad_asm, "9ad_kernelI") == 64              # T x REG x FIX x EVAP x BIG, two sweeps each
-    assert isa.check_prefetch_distance(ad_asm, "9ad_kernelIdLb1ELb0ELb0ELb0E") == 2  # the drivers' default
+    assert isa.check_prefetch_distance(ad_asm, "9ad_kernelI") == 72              # T x REG x FIX x EVAP x BIG, two sweeps each; + 8 trajectory, one
+    assert isa.check_prefetch_distance(ad_asm, "9ad_kernelIdLb1ELb0ELb0ELb0ELb0E") == 2  # the drivers' default
 
 
 def test_prefetch_guard_detects_a_wait_behind_the_loads(ad_asm):
@@ -76,13 +76,13 @@ def test_prefetch_guard_detects_a_wait_behind_the_loads(ad_asm):
     kernel's second sweep, must trip the guard."""
     import re
 
-    k0 = ad_asm.index("_ZN3cs29ad_kernelIdLb1ELb0ELb0ELb0E")
+    k0 = ad_asm.index("_ZN3cs29ad_kernelIdLb1ELb0ELb0ELb0ELb0E")
     k1 = ad_asm.index(".end_amdhsa_kernel", k0)
     loads = [m.end() for m in re.finditer(r"global_load_dwordx2 [^\n]*\n", ad_asm[k0:k1])]
     at = k0 + loads[-1]                      # the last ordinary load of the kernel: sweep 2's prefetch batch
     mutated = ad_asm[:at] + "\ts_waitcnt vmcnt(3)\n" + ad_asm[at:]
     with pytest.raises(AssertionError, match="waited for"):
-        isa.check_prefetch_distance(mutated, "9ad_kernelIdLb1ELb0ELb0ELb0E")
+        isa.check_prefetch_distance(mutated, "9ad_kernelIdLb1ELb0ELb0ELb0ELb0E")
 
 
 def test_register_budgets_of_the_default_kernels(nl_asm, tl_asm, ad_asm):
